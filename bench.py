@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the path-trace hot path on MI355X (BASELINE.json metric).
+
+A "step" is one whole render of the workload.  At N=1 the workload is BASELINE configs[2]:
+1920x1080, spp=64, max_depth=8 on the reference's own scene (create_scene() of
+src/spira-metal-optimized.jl:429-510 with main()'s camera :1499-1505), synthetic by construction.
+At N>1 the frame is tile-sharded over the ranks (interleaved 8-row stripes, one process per GPU,
+no collective while rendering, ONE RCCL gather of the tiles per step) and spp = 64*N, so the
+per-GPU work is fixed ("weak").  Scene and camera are uploaded per render (a few hundred bytes);
+outputs stay in HBM.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (k_bounce) from a
+separate, event-bracketed render after the timed region; `cpu_baseline` times the CPU oracle
+(a port: the Julia reference cannot run here) on the host cores, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.join(ROOT, "julia-spira_amd"), os.path.join(ROOT, "oracle")]
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(c, prec_bytes):
+    """HBM bytes the wavefront formulation must move (DESIGN.md "Roofline"), from device counters:
+    every enqueued ray is written once and read once (10 values), every path stores its first radiance
+    term (4 values), every later contributing segment read-modify-writes it (2 x 4 values)."""
+    return (2 * 10 * c["rays_enqueued"] + 4 * c["samples"] + 8 * c["radiance_rmw"]) * prec_bytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64, help="samples per pixel PER GPU (total = spp * gpus)")
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "mega"])
+    ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from spira_hip import _binding as B
+    from spira_hip import distributed as D
+    from spira_hip import scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    B.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, depth = args.width, args.height, args.depth
+    spp_total = args.spp * world
+    s = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3}[args.scene]()
+    sc = (s["spheres5"], s["materials8"], s["triangles10"], s["camera12"])
+    ns, nm = len(s["spheres5"]), len(s["materials8"])
+    nt = 0 if s["triangles10"] is None else len(s["triangles10"])
+    kflag = B.KERNEL_MEGA if args.kernel == "mega" else B.KERNEL_WAVEFRONT
+    tile = D.tile_params(H, world, rank)
+    rows = tile["rows"] or H
+    params = B.make_params(W, H, spp_total, depth, ns, nm, nt, flags=kflag | B.POST_NONE, seed=scenes.seed_for(3), **tile)
+    tdt = torch.float32 if args.prec == "f32" else torch.float64
+    out = torch.empty((3, rows, W), dtype=tdt, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        B.render_device(*sc, params, out.data_ptr(), 0, stream.cuda_stream, args.prec)
+        return D.gather_image(out, H) if world > 1 else out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    c_timed = B.counters()
+    samples_per_step = W * H * spp_total
+    value = samples_per_step * args.steps / dt / 1e6
+
+    result = None
+    if rank == 0:
+        assert bool(torch.isfinite(img).all()), "non-finite pixels"
+        # ---- roofline leg: one extra render with every bounce launch bracketed by HIP events
+        roof = None
+        if args.kernel == "wavefront":
+            pp = B.make_params(W, H, spp_total, depth, ns, nm, nt, flags=kflag | B.POST_NONE | B.FLAG_PROFILE,
+                               seed=scenes.seed_for(3), **tile)
+            B.render_device(*sc, pp, out.data_ptr(), 0, stream.cuda_stream, args.prec)
+            torch.cuda.synchronize()
+            c = B.counters()
+            nbytes = algorithmic_bytes(c, 4 if args.prec == "f32" else 8)
+            launches = max(1, c["bounce_launches"])
+            avg_ms = c["bounce_kernel_ms"] / launches
+            achieved = nbytes / (c["bounce_kernel_ms"] * 1e-3) / 1e9 if c["bounce_kernel_ms"] > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                    "bytes_per_sample": round(nbytes / c["samples"], 2), "segments_per_sample": round(c["segments"] / c["samples"], 4),
+                    "bounce_kernel_share": round(c["bounce_kernel_ms"] / max(c["kernel_ms"], 1e-9), 4)}
+        # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_py as O
+            cores = O.max_threads()
+            t1 = time.perf_counter()
+            O.render(*sc, O.make_params(W, H, 1, depth, ns, nm, nt, seed=scenes.seed_for(3), row0=H // 2, rows=32), "f64", n_threads=cores)
+            cal = time.perf_counter() - t1
+            rate = 32 * W / max(cal, 1e-6)                       # samples/s from the calibration slab
+            cpu_spp = max(1, min(args.spp, int(rate * args.cpu_seconds / (W * H))))
+            t1 = time.perf_counter()
+            O.render(*sc, O.make_params(W, H, cpu_spp, depth, ns, nm, nt, seed=scenes.seed_for(3)), "f64", n_threads=cores)
+            cdt = time.perf_counter() - t1
+            cpu = {"value": round(W * H * cpu_spp / cdt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                   "sample": "%dx%d spp=%d depth=%d, same scene/seed, Float64 oracle (oracle/spira_oracle.c, OpenMP over rows), %.1f s"
+                             % (W, H, cpu_spp, depth, cdt)}
+        result = {
+            "metric": "Msamples/sec at 1920x1080 spp=64 depth=8; fraction of HBM roofline",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %dx%d spp=%d depth=%d, scene %s (%s), semantics A, %s kernels, tile-sharded "
+                                   "over %d GPU(s) in 8-row stripes + one RCCL gather" %
+                                   (W, H, spp_total, depth, args.scene,
+                                    {"s1": "create_scene() of src/spira-metal-optimized.jl", "s2": "create_scene() of examples/julia-raytracer.jl",
+                                     "s3": "S1 inside a closed box"}[args.scene], args.kernel, world),
+                       "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": args.scene, "kernel": args.kernel,
+                       "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
+                       "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,538 @@
+// spira_device.h — gfx950 device code of the SPIRA path-trace hot path (HIP, CDNA4 only).
+//
+// One ray per lane.  The per-segment arithmetic follows examples/julia-raytracer.jl of the
+// reference statement by statement (citations inline) so that path GEOMETRY is bit-identical
+// to a same-precision CPU evaluation; the translation unit is built with -ffp-contract=off
+// because Julia never fuses a*b+c.  Everything else (iterative throughput form, SoA queues,
+// compaction, LDS scene, counter-based RNG) is this build's own design — see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spira {
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr uint32_t kMaxTries = 64;   // bounded rejection sampling (P(exhaust) ~ 2e-21)
+constexpr size_t kCompactScratchBytes = 96;   // [kBlock/64 + 1][4] uint32 behind the LDS scene
+
+// ------------------------------------------------------------------ small vector algebra
+// Operation order mirrors Vec3 of examples/julia-raytracer.jl:11-41.
+template <class T> struct Vec { T x, y, z; };
+
+template <class T> __device__ __forceinline__ Vec<T> mk(T x, T y, T z) { Vec<T> r; r.x = x; r.y = y; r.z = z; return r; }
+template <class T> __device__ __forceinline__ Vec<T> operator+(Vec<T> a, Vec<T> b) { return mk<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> __device__ __forceinline__ Vec<T> operator-(Vec<T> a, Vec<T> b) { return mk<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> __device__ __forceinline__ Vec<T> operator*(Vec<T> a, T b) { return mk<T>(a.x * b, a.y * b, a.z * b); }
+template <class T> __device__ __forceinline__ Vec<T> operator/(Vec<T> a, T b) { return mk<T>(a.x / b, a.y / b, a.z / b); }
+template <class T> __device__ __forceinline__ Vec<T> mulv(Vec<T> a, Vec<T> b) { return mk<T>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <class T> __device__ __forceinline__ T dot(Vec<T> a, Vec<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> __device__ __forceinline__ Vec<T> cross(Vec<T> a, Vec<T> b) {
+    return mk<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }   // correctly rounded (hipcc default)
+__device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
+__device__ __forceinline__ float abs_t(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double abs_t(double x) { return __builtin_fabs(x); }
+template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a) { return a / sqrt_rn(dot(a, a)); }  // :27-28
+
+// ------------------------------------------------------------------ 16/32-byte packets
+template <class T> struct alignas(4 * sizeof(T)) Pack4 { T x, y, z, w; };
+template <class T> struct alignas(2 * sizeof(T)) Pack2 { T x, y; };
+
+template <class T> struct Bits;
+template <> struct Bits<float> {
+    static __device__ __forceinline__ float from_u32(uint32_t u) { return __uint_as_float(u); }
+    static __device__ __forceinline__ uint32_t to_u32(float f) { return __float_as_uint(f); }
+};
+template <> struct Bits<double> {
+    static __device__ __forceinline__ double from_u32(uint32_t u) { return __longlong_as_double((long long)u); }
+    static __device__ __forceinline__ uint32_t to_u32(double f) { return (uint32_t)__double_as_longlong(f); }
+};
+
+// ------------------------------------------------------------------ counter-based RNG (DESIGN.md "RNG")
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // lowbias32
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+struct RngKey { uint32_t hA, hB, hBr; };
+__device__ __forceinline__ RngKey rng_key(uint32_t sA, uint32_t sB, uint32_t pixel, uint32_t sample, uint32_t bounce) {
+    uint32_t sb = (sample << 8) | bounce;
+    RngKey k;
+    k.hA = mix32(mix32(sA + pixel) ^ sb);
+    k.hB = mix32(mix32(sB ^ pixel) + sb);
+    k.hBr = (k.hB << 16) | (k.hB >> 16);
+    return k;
+}
+template <class T> __device__ __forceinline__ void rng3(const RngKey &k, uint32_t t, T &u0, T &u1, T &u2) {
+    uint32_t a = mix32((k.hA + t * 0x9E3779B9u) ^ k.hBr);
+    uint32_t b = mix32(a + k.hB);
+    const T s = (T)(1.0 / 2097152.0);
+    u0 = (T)(a >> 11) * s;
+    u1 = (T)(b >> 11) * s;
+    u2 = (T)(((a & 0x7FFu) << 10) | (b & 0x3FFu)) * s;
+}
+
+// ------------------------------------------------------------------ scene in LDS
+// Layout of the dynamic LDS block (all offsets multiples of 32 bytes):
+//   sph  : n_spheres   x Pack4<T>  {cx, cy, cz, r*r}   (one ds_read_b128 per sphere test, f32)
+//   tri  : n_triangles x 3 x Pack4<T> {v0,0} {e1,0} {e2,0}
+//   mat  : n_materials x 2 x Pack4<T> {diffuse, specular} {emission, roughness}
+//   smat : n_spheres   x int32 (0-based material)   tmat : n_triangles x int32
+template <class T> struct SceneLds {
+    const Pack4<T> *sph;
+    const Pack4<T> *tri;
+    const Pack4<T> *mat;
+    const int *smat;
+    const int *tmat;
+    uint32_t n_spheres, n_triangles;
+};
+
+template <class T> struct SceneGlobal {     // flat arrays exactly as passed through the C ABI
+    const T *spheres5;      // prepare_scene_data, src/spira-metal-optimized.jl:515-529
+    const T *materials8;    // :531-541
+    const T *triangles10;
+    uint32_t n_spheres, n_materials, n_triangles;
+};
+
+template <class T> __host__ __device__ inline size_t scene_lds_bytes(uint32_t ns, uint32_t nm, uint32_t nt) {
+    size_t b = (size_t)ns * sizeof(Pack4<T>) + (size_t)nt * 3 * sizeof(Pack4<T>) + (size_t)nm * 2 * sizeof(Pack4<T>);
+    b += ((size_t)ns + nt) * sizeof(int);
+    return (b + 31) & ~(size_t)31;
+}
+
+template <class T>
+__device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsigned char *lds) {
+    Pack4<T> *sph = reinterpret_cast<Pack4<T> *>(lds);
+    Pack4<T> *tri = sph + g.n_spheres;
+    Pack4<T> *mat = tri + 3 * (size_t)g.n_triangles;
+    int *smat = reinterpret_cast<int *>(mat + 2 * (size_t)g.n_materials);
+    int *tmat = smat + g.n_spheres;
+    for (uint32_t i = threadIdx.x; i < g.n_spheres; i += blockDim.x) {
+        const T *s = g.spheres5 + 5 * (size_t)i;
+        Pack4<T> p; p.x = s[0]; p.y = s[1]; p.z = s[2]; p.w = s[3] * s[3];     // radius*radius, :117
+        sph[i] = p;
+        smat[i] = (int)s[4] - 1;                                               // 1-based float -> 0-based
+    }
+    for (uint32_t i = threadIdx.x; i < g.n_triangles; i += blockDim.x) {
+        const T *t = g.triangles10 + 10 * (size_t)i;
+        Pack4<T> v0, e1, e2;
+        v0.x = t[0]; v0.y = t[1]; v0.z = t[2]; v0.w = 0;
+        e1.x = t[3] - t[0]; e1.y = t[4] - t[1]; e1.z = t[5] - t[2]; e1.w = 0;  // edge1 = v1 - v0, :149
+        e2.x = t[6] - t[0]; e2.y = t[7] - t[1]; e2.z = t[8] - t[2]; e2.w = 0;  // edge2 = v2 - v0, :150
+        tri[3 * i] = v0; tri[3 * i + 1] = e1; tri[3 * i + 2] = e2;
+        tmat[i] = (int)t[9] - 1;
+    }
+    for (uint32_t i = threadIdx.x; i < g.n_materials; i += blockDim.x) {
+        const T *m = g.materials8 + 8 * (size_t)i;
+        Pack4<T> a, b;
+        a.x = m[0]; a.y = m[1]; a.z = m[2]; a.w = m[6];     // diffuse|albedo, specular|metallic
+        b.x = m[3]; b.y = m[4]; b.z = m[5]; b.w = m[7];     // emission, roughness
+        mat[2 * i] = a; mat[2 * i + 1] = b;
+    }
+    __syncthreads();
+    SceneLds<T> sc;
+    sc.sph = sph; sc.tri = tri; sc.mat = mat; sc.smat = smat; sc.tmat = tmat;
+    sc.n_spheres = g.n_spheres; sc.n_triangles = g.n_triangles;
+    return sc;
+}
+
+// ------------------------------------------------------------------ per-render constants
+template <class T> struct RenderConst {
+    Vec<T> cam_origin, cam_llc, cam_hor, cam_ver;
+    uint32_t width, height;      // full image
+    uint32_t spp, max_depth;
+    uint32_t sA, sB;             // mixed seed halves
+    uint32_t flags;
+    // tile
+    uint32_t rows;               // rows rendered by this call
+    uint32_t row0, stripe_h, stripe_count, stripe_rank;
+    uint32_t tile_pixels;        // rows * width
+    uint32_t slots;              // k: sample slots per pass
+};
+
+// local output row -> reference loop row j (1-based, j = 1 is v = 0, the image bottom)
+template <class T> __device__ __forceinline__ uint32_t ref_row_j(const RenderConst<T> &rc, uint32_t lr) {
+    uint32_t y = rc.stripe_count > 1 ? ((lr / rc.stripe_h) * rc.stripe_count + rc.stripe_rank) * rc.stripe_h + (lr % rc.stripe_h)
+                                     : rc.row0 + lr;
+    return (rc.flags & 0x00001000u /*SPIRA_ROWS_BOTTOM_UP*/) ? y + 1 : rc.height - y;   // hdr_data[height-j+1, i], :408
+}
+
+// ------------------------------------------------------------------ closest hit (semantics A)
+// Linear scan with a shrinking t_max, examples/julia-raytracer.jl:242-258; spheres :113-142,
+// triangles :145-187.  Returns the object index (spheres first, then triangles) or -1.
+template <class T>
+__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit) {
+    T closest = (T)INFINITY;                                   // t_max = Inf, :335
+    int prim = -1;
+    const T a = dot(d, d);                                     // :115 (same value for every sphere)
+    const T two_a = (T)2.0 * a;
+    const T four_a = (T)4 * a;
+    for (uint32_t s = 0; s < sc.n_spheres; ++s) {
+        const Pack4<T> c = sc.sph[s];
+        Vec<T> oc = o - mk<T>(c.x, c.y, c.z);                  // :114
+        T b = (T)2.0 * dot(oc, d);                             // :116
+        T cc = dot(oc, oc) - c.w;                              // :117
+        T disc = b * b - four_a * cc;                          // :118
+        if (!(disc < 0)) {                                     // :120
+            T sq = sqrt_rn(disc);                              // :125
+            T root = (-b - sq) / two_a;                        // :126
+            if (root < t_min || root > closest) {              // :130
+                root = (-b + sq) / two_a;                      // :127,:131
+                if (root < t_min || root > closest) continue;  // :132
+            }
+            closest = root; prim = (int)s;                     // :137, :252
+        }
+    }
+    for (uint32_t i = 0; i < sc.n_triangles; ++i) {
+        const Pack4<T> v0 = sc.tri[3 * i], e1p = sc.tri[3 * i + 1], e2p = sc.tri[3 * i + 2];
+        Vec<T> e1 = mk<T>(e1p.x, e1p.y, e1p.z), e2 = mk<T>(e2p.x, e2p.y, e2p.z);
+        Vec<T> h = cross(d, e2);                               // :153
+        T aa = dot(e1, h);                                     // :154
+        if (abs_t(aa) < (T)1e-8) continue;                      // :157
+        T f = (T)1.0 / aa;                                     // :161
+        Vec<T> sv = o - mk<T>(v0.x, v0.y, v0.z);               // :162
+        T u = f * dot(sv, h);                                  // :163
+        if (u < (T)0.0 || u > (T)1.0) continue;                // :165
+        Vec<T> q = cross(sv, e1);                              // :169
+        T v = f * dot(d, q);                                   // :170
+        if (v < (T)0.0 || u + v > (T)1.0) continue;            // :172
+        T t = f * dot(e2, q);                                  // :177
+        if (t < t_min || t > closest) continue;                // :179
+        closest = t; prim = (int)(sc.n_spheres + i);
+    }
+    t_hit = closest;
+    return prim;
+}
+
+// random_in_unit_sphere, examples/julia-raytracer.jl:309-316; tries t = 1..kMaxTries.
+template <class T> __device__ __forceinline__ Vec<T> random_in_unit_sphere(const RngKey &k) {
+    Vec<T> p = mk<T>(0, 0, 0);
+    for (uint32_t t = 1; t <= kMaxTries; ++t) {
+        T u0, u1, u2;
+        rng3<T>(k, t, u0, u1, u2);
+        Vec<T> q = mk<T>(u0, u1, u2) * (T)2.0 - mk<T>(1, 1, 1);     // :311
+        if (dot(q, q) < (T)1.0) { p = q; break; }                   // :312
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------ one path segment (semantics A)
+// ray_color, examples/julia-raytracer.jl:328-367, in iterative form:
+//   L += beta * emission ; beta *= specular*diffuse | 0.5*diffuse ; on a miss L += beta * sky.
+struct SegInfo { int prim; bool alive; bool has_contrib; };
+
+template <class T>
+__device__ __forceinline__ SegInfo trace_segment(const SceneLds<T> &sc, const RenderConst<T> &rc, Vec<T> &o, Vec<T> &d,
+                                                 Vec<T> &beta, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                                                 bool scatter, Vec<T> &contrib, T &t_out) {
+    SegInfo info;
+    T t;
+    int prim = closest_hit<T>(sc, o, d, (T)0.001, t);                        // :335
+    info.prim = prim;
+    t_out = prim >= 0 ? t : (T)0;
+    if (prim < 0) {                                                          // miss: sky, :365-366
+        T ts = (T)0.5 * (d.y + (T)1.0);
+        Vec<T> sky = mk<T>(1.0, 1.0, 1.0) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts;
+        contrib = mulv(beta, sky);
+        info.alive = false; info.has_contrib = true;
+        return info;
+    }
+    Vec<T> pos = o + d * t;                                                  // point_at, :138 / :183
+    Vec<T> n;
+    int mi;
+    if (prim < (int)sc.n_spheres) {
+        const Pack4<T> c = sc.sph[prim];
+        n = normalize(pos - mk<T>(c.x, c.y, c.z));                           // :139
+        mi = sc.smat[prim];
+    } else {
+        int ti = prim - (int)sc.n_spheres;
+        const Pack4<T> e1p = sc.tri[3 * ti + 1], e2p = sc.tri[3 * ti + 2];
+        n = normalize(cross(mk<T>(e1p.x, e1p.y, e1p.z), mk<T>(e2p.x, e2p.y, e2p.z)));   // :105-109
+        mi = sc.tmat[ti];
+    }
+    const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
+    Vec<T> diffuse = mk<T>(ma.x, ma.y, ma.z), emission = mk<T>(mb.x, mb.y, mb.z);
+    T specular = ma.w, roughness = mb.w;
+    info.has_contrib = (emission.x != 0 || emission.y != 0 || emission.z != 0);
+    contrib = mulv(beta, emission);                                          // emitted, :339
+    info.alive = scatter;
+    if (scatter) {
+        bool is_spec = specular > (T)0.0;                                    // :342
+        bool need_rnd = is_spec ? (roughness > (T)0.0) : true;               // :346 / :356
+        Vec<T> rnd = mk<T>(0, 0, 0);
+        if (need_rnd) rnd = random_in_unit_sphere<T>(rng_key(rc.sA, rc.sB, pixel, sample, bounce));
+        Vec<T> nd;
+        if (is_spec) {
+            Vec<T> reflected = d - n * ((T)2 * dot(d, n));                   // reflect, :323-325, :344
+            if (roughness > (T)0.0) reflected = reflected + rnd * roughness; // :347
+            nd = normalize(reflected);                                       // :349
+            beta = mulv(beta * specular, diffuse);                           // :353
+        } else {
+            Vec<T> target = (pos + n) + rnd;                                 // :356
+            nd = normalize(target - pos);                                    // :357
+            beta = mulv(beta * (T)0.5, diffuse);                             // :360
+        }
+        o = pos; d = nd;
+    }
+    return info;
+}
+
+// Camera ray for (reference loop indices i, j; both 1-based) — examples/julia-raytracer.jl:398-400, :298-306
+template <class T>
+__device__ __forceinline__ void camera_ray(const RenderConst<T> &rc, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
+                                           Vec<T> &o, Vec<T> &d) {
+    T xu, xv, unused;
+    rng3<T>(rng_key(rc.sA, rc.sB, pixel, sample, 0), 0, xu, xv, unused);
+    T u = ((T)(i - 1) + xu) / (T)(rc.width - 1);                             // :398
+    T v = ((T)(j - 1) + xv) / (T)(rc.height - 1);                            // :399
+    o = rc.cam_origin;
+    d = normalize(((rc.cam_llc + rc.cam_hor * u) + rc.cam_ver * v) - o);     // :303
+}
+
+// q (index inside the pass batch, slot-major) -> pixel / sample
+template <class T>
+__device__ __forceinline__ void path_of(const RenderConst<T> &rc, uint32_t q, uint32_t pass, uint32_t &i, uint32_t &j,
+                                        uint32_t &pixel, uint32_t &sample) {
+    uint32_t slot = q / rc.tile_pixels;
+    uint32_t pl = q - slot * rc.tile_pixels;
+    uint32_t lr = pl / rc.width;
+    uint32_t lx = pl - lr * rc.width;
+    j = ref_row_j(rc, lr);
+    i = lx + 1;
+    pixel = (j - 1) * rc.width + lx;
+    sample = pass * rc.slots + slot;
+}
+
+// ------------------------------------------------------------------ ray queues (SoA of 16/32-byte packets)
+// A[i] = {o.x o.y o.z d.x}  B[i] = {d.y d.z beta.x beta.y}  C[i] = {beta.z, bits(q)}   — 40 B (f32) / 80 B (f64) per ray
+template <class T> struct RayQueue { Pack4<T> *A; Pack4<T> *B; Pack2<T> *C; };
+
+struct Stats {                       // device-side counters (one per context)
+    unsigned long long segments, rays_enqueued, radiance_rmw;
+};
+
+template <class T> struct BounceArgs {
+    SceneGlobal<T> scene;
+    RenderConst<T> rc;
+    RayQueue<T> qin, qout;
+    Pack4<T> *L;                     // per-path radiance of the pass batch (slot-major), 16/32 B each
+    uint32_t *counts;                // counts[b] = rays entering bounce b (b >= 1)
+    Stats *stats;
+    uint32_t bounce;
+    uint32_t pass;
+    uint32_t n_first;                // FIRST: number of paths in this pass
+};
+
+// Per-bounce wavefront kernel.  FIRST generates the camera ray in registers (no queue read)
+// and stores the path's first radiance term; later bounces read compacted rays, RMW the path
+// radiance only when the segment contributes, and append survivors to the other queue.
+// Compaction: wave64 ballot + popcount prefix, per-block aggregation in LDS, ONE global
+// atomicAdd per block per R*256 rays; survivors of a wave land in consecutive queue slots,
+// so the 16-byte packet stores coalesce.
+template <class T, bool FIRST, int R>
+__global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    // compaction scratch lives behind the scene in the one dynamic LDS block (no static __shared__
+    // in front of it, so the base stays 32-byte aligned)
+    uint32_t(*s_wave_cnt)[4] = reinterpret_cast<uint32_t(*)[4]>(
+        lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles));   // [kBlock/64][4 >= R]
+    uint32_t &s_base = s_wave_cnt[kBlock / 64][0];
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    const RenderConst<T> &rc = a.rc;
+
+    const uint32_t n_in = FIRST ? a.n_first : a.counts[a.bounce];
+    const bool scatter = (a.bounce + 1 < rc.max_depth);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr uint32_t CH = kBlock * R;
+    unsigned long long n_rmw = 0;
+
+    for (uint32_t base = blockIdx.x * CH; base < n_in; base += gridDim.x * CH) {
+        Vec<T> o[R], d[R], beta[R];
+        uint32_t q[R];
+        bool alive[R];
+        uint32_t pre[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t idx = base + r * kBlock + threadIdx.x;
+            alive[r] = false;
+            if (idx < n_in) {
+                uint32_t pixel, sample, pi, pj;
+                if (FIRST) {
+                    q[r] = idx;
+                    path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
+                    camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d[r]);
+                    beta[r] = mk<T>(1, 1, 1);
+                } else {
+                    const Pack4<T> A = a.qin.A[idx], B = a.qin.B[idx];
+                    const Pack2<T> C = a.qin.C[idx];
+                    o[r] = mk<T>(A.x, A.y, A.z);
+                    d[r] = mk<T>(A.w, B.x, B.y);
+                    beta[r] = mk<T>(B.z, B.w, C.x);
+                    q[r] = Bits<T>::to_u32(C.y);
+                    path_of<T>(rc, q[r], a.pass, pi, pj, pixel, sample);
+                }
+                Vec<T> contrib; T t_hit;
+                SegInfo si = trace_segment<T>(sc, rc, o[r], d[r], beta[r], pixel, sample, a.bounce, scatter, contrib, t_hit);
+                if (FIRST) {
+                    Pack4<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z; l.w = 0;
+                    if (!si.has_contrib) { l.x = 0; l.y = 0; l.z = 0; }
+                    a.L[q[r]] = l;
+                } else if (si.has_contrib) {
+                    Pack4<T> l = a.L[q[r]];
+                    l.x += contrib.x; l.y += contrib.y; l.z += contrib.z;
+                    a.L[q[r]] = l;
+                    ++n_rmw;
+                }
+                alive[r] = si.alive;
+            }
+            const unsigned long long m = __ballot(alive[r]);
+            pre[r] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave_cnt[wave][r] = __popcll(m);
+        }
+        if (scatter) {           // uniform: the last bounce never enqueues
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    for (int w = 0; w < kBlock / 64; ++w) tot += s_wave_cnt[w][r];
+                s_base = tot ? atomicAdd(&a.counts[a.bounce + 1], tot) : 0u;
+            }
+            __syncthreads();
+            uint32_t off = s_base;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int w = 0; w < kBlock / 64; ++w) {
+                    const uint32_t c = s_wave_cnt[w][r];
+                    if (w == (int)wave && alive[r]) {
+                        const uint32_t dst = off + pre[r];
+                        Pack4<T> A, B; Pack2<T> C;
+                        A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = d[r].x;
+                        B.x = d[r].y; B.y = d[r].z; B.z = beta[r].x; B.w = beta[r].y;
+                        C.x = beta[r].z; C.y = Bits<T>::from_u32(q[r]);
+                        a.qout.A[dst] = A; a.qout.B[dst] = B; a.qout.C[dst] = C;
+                    }
+                    off += c;
+                }
+            }
+            __syncthreads();     // s_wave_cnt / s_base are rewritten by the next chunk
+        }
+    }
+    // statistics: one atomic per block
+    if (!FIRST) {
+        for (int sft = 32; sft > 0; sft >>= 1) n_rmw += __shfl_down(n_rmw, sft);
+        if (lane == 0 && n_rmw) atomicAdd(&a.stats->radiance_rmw, n_rmw);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&a.stats->segments, (unsigned long long)n_in);
+        if (!FIRST) atomicAdd(&a.stats->rays_enqueued, (unsigned long long)n_in);
+    }
+}
+
+// Megakernel: one thread walks one whole path in registers (the non-wavefront comparison point).
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_mega(const BounceArgs<T> a) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    const RenderConst<T> &rc = a.rc;
+    unsigned long long nseg = 0;
+    for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < a.n_first; idx += gridDim.x * kBlock) {
+        uint32_t pixel, sample, pi, pj;
+        Vec<T> o, d, beta = mk<T>(1, 1, 1), Lacc = mk<T>(0, 0, 0);
+        path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
+        camera_ray<T>(rc, pi, pj, pixel, sample, o, d);
+        for (uint32_t b = 0; b < rc.max_depth; ++b) {
+            Vec<T> contrib; T t_hit;
+            SegInfo si = trace_segment<T>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
+            ++nseg;
+            if (b == 0) { if (si.has_contrib) Lacc = contrib; }
+            else if (si.has_contrib) Lacc = Lacc + contrib;
+            if (!si.alive) break;
+        }
+        Pack4<T> l; l.x = Lacc.x; l.y = Lacc.y; l.z = Lacc.z; l.w = 0;
+        a.L[idx] = l;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
+    if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
+}
+
+// Diagnostic: trace chosen paths and record every segment (prim, t, direction) — used by the
+// parity tests to compare path geometry bit for bit with the CPU restatement.
+template <class T>
+__global__ __launch_bounds__(64) void k_trace(const BounceArgs<T> a, const uint32_t *ijs, uint32_t n_paths, int *prims, T *ts,
+                                              T *dirs, T *radiance) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    const RenderConst<T> &rc = a.rc;
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
+    uint32_t i = ijs[3 * p], j = ijs[3 * p + 1], sample = ijs[3 * p + 2];
+    uint32_t pixel = (j - 1) * rc.width + (i - 1);
+    Vec<T> o, d, beta = mk<T>(1, 1, 1), Lacc = mk<T>(0, 0, 0);
+    camera_ray<T>(rc, i, j, pixel, sample, o, d);
+    for (uint32_t b = 0; b < rc.max_depth; ++b) {
+        Vec<T> contrib; T t_hit;
+        Vec<T> dir_in = d;
+        SegInfo si = trace_segment<T>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
+        size_t k = (size_t)p * rc.max_depth + b;
+        prims[k] = si.prim; ts[k] = t_hit;
+        dirs[3 * k] = dir_in.x; dirs[3 * k + 1] = dir_in.y; dirs[3 * k + 2] = dir_in.z;
+        if (b == 0) { if (si.has_contrib) Lacc = contrib; }
+        else if (si.has_contrib) Lacc = Lacc + contrib;
+        if (!si.alive) { for (uint32_t bb = b + 1; bb < rc.max_depth; ++bb) prims[(size_t)p * rc.max_depth + bb] = -2; break; }
+    }
+    radiance[3 * p] = Lacc.x; radiance[3 * p + 1] = Lacc.y; radiance[3 * p + 2] = Lacc.z;
+}
+
+// Per-pass resolve: accum[pix] += L[slot][pix] for slot = 0..k_eff-1, in sample order — the
+// `color = color + ray_color(...)` of examples/julia-raytracer.jl:401 in the same order.
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack4<T> *L, uint32_t tile_pixels, uint32_t k_eff, int first_pass) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < tile_pixels; p += gridDim.x * kBlock) {
+        Pack4<T> acc;
+        if (first_pass) { acc.x = 0; acc.y = 0; acc.z = 0; acc.w = 0; } else acc = accum[p];
+        for (uint32_t s = 0; s < k_eff; ++s) {
+            const Pack4<T> l = L[(size_t)s * tile_pixels + p];
+            acc.x = acc.x + l.x; acc.y = acc.y + l.y; acc.z = acc.z + l.z;
+        }
+        accum[p] = acc;
+    }
+}
+
+// ACES / gamma display transforms (to_acescg examples/julia-raytracer.jl:370-384;
+// gpu_tone_map_kernel! src/spira-metal-optimized.jl:1128-1144; clamp+sqrt :1441-1442)
+template <class T> __host__ __device__ inline T aces1(T x) {
+    const T a = (T)2.51, b = (T)0.03, c = (T)2.43, d = (T)0.59, e = (T)0.14;
+    T v = (x * (a * x + b)) / (x * (c * x + d) + e);
+    return v < 0 ? (T)0 : (v > 1 ? (T)1 : v);
+}
+__host__ __device__ inline float sqrt_any(float x) { return __builtin_sqrtf(x); }
+__host__ __device__ inline double sqrt_any(double x) { return __builtin_sqrt(x); }
+template <class T> __host__ __device__ inline T post1(T x, uint32_t post) {
+    switch (post) {
+    case 0x000u: return aces1<T>(x);
+    case 0x100u: return sqrt_any(aces1<T>(x));
+    case 0x200u: { T v = x < 0 ? (T)0 : (x > 1 ? (T)1 : x); return sqrt_any(v); }
+    default: return x;
+    }
+}
+
+// Finalize: color / samples_per_pixel (:405), planar outputs, optional display transform.
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_finalize(const Pack4<T> *accum, uint32_t tile_pixels, uint32_t spp, uint32_t post,
+                                                     T *out_hdr, T *out_img) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < tile_pixels; p += gridDim.x * kBlock) {
+        const Pack4<T> acc = accum[p];
+        T r = acc.x / (T)spp, g = acc.y / (T)spp, b = acc.z / (T)spp;
+        if (out_hdr) { out_hdr[p] = r; out_hdr[tile_pixels + p] = g; out_hdr[2 * (size_t)tile_pixels + p] = b; }
+        if (out_img) {
+            out_img[p] = post1<T>(r, post); out_img[tile_pixels + p] = post1<T>(g, post);
+            out_img[2 * (size_t)tile_pixels + p] = post1<T>(b, post);
+        }
+    }
+}
+
+}  // namespace spira

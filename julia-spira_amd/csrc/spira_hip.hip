@@ -1,0 +1,525 @@
+// spira_hip.hip — host side of libspira_hip.so: device contexts, workspaces, the wavefront
+// pass loop and the C ABI declared in include/spira_hip.h.  gfx950 (MI355X) only.
+//
+// Replaces the host loops of render_hybrid_gpu (src/spira-metal-optimized.jl:1228-1343): the
+// reference launches >= spp*(1 + max_depth*(12*n_spheres + 4)) synchronous kernels with host
+// round trips per depth; here one pass = 1 memset + max_depth bounce kernels
+// + 1 resolve kernel, fully asynchronous on one HIP stream, the live-ray count staying on the
+// device (counts[]), and a pass carries `slots` samples of every pixel of the tile at once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/spira_hip.h"
+#include "spira_device.h"
+
+
+namespace {
+
+thread_local std::string tl_err;
+thread_local int tl_device = 0;
+
+int fail(int code, const std::string &msg) { tl_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(SPIRA_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(SPIRA_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+};
+
+struct Ctx {
+    bool init = false;
+    int device = -1;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    DevBuf qA[2], qB[2], qC[2], L, accum, counts, stats, scene, out_tmp, trace;
+    spira::Stats *h_stats = nullptr;          // pinned
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> ev_pool;          // profile mode: pairs around bounce launches
+    size_t ev_used = 0;
+    spira_counters last{};
+    bool last_valid = false, last_pending = false;
+    hipStream_t last_stream = nullptr;
+    std::mutex mu;
+};
+
+constexpr int kMaxDevices = 16;
+Ctx g_ctx[kMaxDevices];
+
+int get_ctx(Ctx **out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(SPIRA_E_NO_DEVICE, std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (tl_device < 0 || tl_device >= n || tl_device >= kMaxDevices) return fail(SPIRA_E_INVALID, "device index out of range");
+    Ctx &c = g_ctx[tl_device];
+    HIP_TRY(hipSetDevice(tl_device));
+    if (!c.init) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, tl_device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SPIRA_E_NO_DEVICE, std::string("libspira_hip is built for gfx950 only, found ") + prop.gcnArchName);
+        c.num_cus = prop.multiProcessorCount;
+        c.device = tl_device;
+        HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&c.ev_start));
+        HIP_TRY(hipEventCreate(&c.ev_stop));
+        HIP_TRY(hipHostMalloc((void **)&c.h_stats, sizeof(spira::Stats), hipHostMallocDefault));
+        c.init = true;
+    }
+    *out = &c;
+    return 0;
+}
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    return (uint32_t)std::strtoul(s, nullptr, 10);
+}
+
+uint32_t stripe_rows(uint32_t height, uint32_t sh, uint32_t n, uint32_t r) {
+    if (sh == 0 || n == 0) return 0;
+    uint32_t rows = 0;
+    for (uint32_t y0 = r * sh; y0 < height; y0 += n * sh) rows += std::min(sh, height - y0);
+    return rows;
+}
+
+template <class T>
+int validate(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
+             uint32_t *rows_out) {
+    if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    if (!materials8 || !camera12) return fail(SPIRA_E_INVALID, "materials8 / camera12 is NULL");
+    if (p->n_spheres && !spheres5) return fail(SPIRA_E_INVALID, "spheres5 is NULL");
+    if (p->width < 2 || p->height < 2) return fail(SPIRA_E_INVALID, "width and height must be >= 2 (u = (i-1+rand)/(W-1))");
+    if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "image larger than 2^31 pixels");
+    if (p->spp < 1 || p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "spp out of range [1, 2^24]");
+    if (p->max_depth > SPIRA_MAX_DEPTH) return fail(SPIRA_E_LIMIT, "max_depth > 255");
+    if (p->n_materials < 1) return fail(SPIRA_E_INVALID, "n_materials must be >= 1");
+    uint32_t nt = triangles10 ? p->n_triangles : 0;
+    if (p->n_spheres > SPIRA_MAX_LDS_SPHERES || nt > SPIRA_MAX_LDS_TRIANGLES)
+        return fail(SPIRA_E_LIMIT, "scene exceeds the LDS linear-scan limits (1024 spheres / 1024 triangles)");
+    if (spira::scene_lds_bytes<T>(p->n_spheres, p->n_materials, nt) > 150 * 1024)
+        return fail(SPIRA_E_LIMIT, "scene does not fit in LDS");
+    for (uint32_t i = 0; i < p->n_spheres; ++i) {
+        T m = spheres5[5 * (size_t)i + 4];
+        if (!(m >= 1 && m <= (T)p->n_materials) || m != std::floor(m))
+            return fail(SPIRA_E_INVALID, "sphere material index out of range (1-based, stored as a float)");
+    }
+    for (uint32_t i = 0; i < nt; ++i) {
+        T m = triangles10[10 * (size_t)i + 9];
+        if (!(m >= 1 && m <= (T)p->n_materials) || m != std::floor(m))
+            return fail(SPIRA_E_INVALID, "triangle material index out of range");
+    }
+    if ((p->flags & SPIRA_SEM_MASK) != SPIRA_SEM_A) return fail(SPIRA_E_UNSUPPORTED, "only SPIRA_SEM_A is implemented");
+    uint32_t kern = p->flags & SPIRA_KERNEL_MASK;
+    if (kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
+    uint32_t rows = p->rows;
+    if (rows == 0) rows = p->height;
+    else if (p->stripe_count > 1) {
+        if (p->stripe_h == 0 || p->stripe_rank >= p->stripe_count) return fail(SPIRA_E_INVALID, "bad stripe parameters");
+        if (rows != stripe_rows(p->height, p->stripe_h, p->stripe_count, p->stripe_rank))
+            return fail(SPIRA_E_INVALID, "rows != spira_stripe_rows(height, stripe_h, stripe_count, stripe_rank)");
+    } else if ((uint64_t)p->row0 + rows > p->height) return fail(SPIRA_E_INVALID, "row0 + rows > height");
+    *rows_out = rows;
+    return 0;
+}
+
+template <class T>
+void fill_const(spira::RenderConst<T> &rc, const T *cam, const spira_params *p, uint32_t rows, uint32_t slots) {
+    rc.cam_origin = {cam[0], cam[1], cam[2]};
+    rc.cam_llc = {cam[3], cam[4], cam[5]};
+    rc.cam_hor = {cam[6], cam[7], cam[8]};
+    rc.cam_ver = {cam[9], cam[10], cam[11]};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
+    uint32_t lo = (uint32_t)p->seed, hi = (uint32_t)(p->seed >> 32);
+    rc.sA = spira::mix32(spira::mix32(lo + 0x9E3779B9u) ^ hi);
+    rc.sB = spira::mix32(spira::mix32(hi + 0x85EBCA6Bu) ^ lo);
+    rc.flags = p->flags;
+    rc.rows = rows;
+    if (p->rows == 0) { rc.row0 = 0; rc.stripe_h = 0; rc.stripe_count = 0; rc.stripe_rank = 0; }
+    else { rc.row0 = p->row0; rc.stripe_h = p->stripe_h; rc.stripe_count = p->stripe_count; rc.stripe_rank = p->stripe_rank; }
+    rc.tile_pixels = rows * p->width;
+    rc.slots = slots;
+}
+
+// Upload the flat scene arrays into one device buffer; returns device pointers in `g`.
+template <class T>
+int upload_scene(Ctx &c, hipStream_t st, const T *spheres5, const T *materials8, const T *triangles10, const spira_params *p,
+                 spira::SceneGlobal<T> &g) {
+    uint32_t nt = triangles10 ? p->n_triangles : 0;
+    size_t ns_b = (size_t)p->n_spheres * 5 * sizeof(T), nm_b = (size_t)p->n_materials * 8 * sizeof(T), nt_b = (size_t)nt * 10 * sizeof(T);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t total = up(ns_b) + up(nm_b) + up(nt_b) + 256;
+    if (int rc = c.scene.ensure(total)) return rc;
+    char *base = (char *)c.scene.p;
+    g.spheres5 = (const T *)base;
+    g.materials8 = (const T *)(base + up(ns_b));
+    g.triangles10 = (const T *)(base + up(ns_b) + up(nm_b));
+    g.n_spheres = p->n_spheres; g.n_materials = p->n_materials; g.n_triangles = nt;
+    if (ns_b) HIP_TRY(hipMemcpyAsync((void *)g.spheres5, spheres5, ns_b, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync((void *)g.materials8, materials8, nm_b, hipMemcpyHostToDevice, st));
+    if (nt_b) HIP_TRY(hipMemcpyAsync((void *)g.triangles10, triangles10, nt_b, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+template <class T, bool FIRST>
+void launch_bounce(int R, dim3 grid, size_t lds, hipStream_t st, const spira::BounceArgs<T> &a) {
+    switch (R) {
+    case 4: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 4>), grid, dim3(spira::kBlock), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 2>), grid, dim3(spira::kBlock), lds, st, a); break;
+    default: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 1>), grid, dim3(spira::kBlock), lds, st, a); break;
+    }
+}
+
+int profile_events(Ctx &c, size_t need) {
+    while (c.ev_pool.size() < need) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c.ev_pool.push_back(e);
+    }
+    return 0;
+}
+
+template <class T>
+int render_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
+                T *out_hdr, T *out_img, bool out_on_device, void *user_stream) {
+    uint32_t rows = 0;
+    if (int rc = validate<T>(spheres5, materials8, triangles10, camera12, p, &rows)) return rc;
+    if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
+    Ctx *cp = nullptr;
+    if (int rc = get_ctx(&cp)) return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::mutex> lock(c.mu);
+    hipStream_t st = out_on_device ? (hipStream_t)user_stream : c.stream;
+
+    const uint32_t W = p->width;
+    const uint64_t tile_pixels = (uint64_t)rows * W;
+    uint32_t target = p->batch_rays ? p->batch_rays : env_u32("SPIRA_BATCH_RAYS", 4u << 20);
+    uint64_t slots64 = std::max<uint64_t>(1, target / tile_pixels);
+    slots64 = std::min<uint64_t>(slots64, p->spp);
+    if (slots64 * tile_pixels > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "tile too large: rows*width must be < 2^31");
+    const uint32_t slots = (uint32_t)slots64;
+    const uint64_t batch = slots64 * tile_pixels;
+    const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA;
+    const bool profile = (p->flags & SPIRA_FLAG_PROFILE) != 0;
+    int R = (int)env_u32("SPIRA_R", 2);
+    if (R != 1 && R != 2 && R != 4) R = 2;
+
+    // ---- workspaces (cached per device, grown on demand; sized for 288 GB HBM: no chunking of a pass)
+    using P4 = spira::Pack4<T>;
+    using P2 = spira::Pack2<T>;
+    if (!mega && p->max_depth > 1)
+        for (int i = 0; i < 2; ++i) {
+            if (int rc = c.qA[i].ensure(batch * sizeof(P4))) return rc;
+            if (int rc = c.qB[i].ensure(batch * sizeof(P4))) return rc;
+            if (int rc = c.qC[i].ensure(batch * sizeof(P2))) return rc;
+        }
+    if (int rc = c.L.ensure(batch * sizeof(P4))) return rc;
+    if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
+    if (int rc = c.counts.ensure((SPIRA_MAX_DEPTH + 2) * sizeof(uint32_t))) return rc;
+    if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
+
+    spira::BounceArgs<T> a{};
+    if (int rc = upload_scene<T>(c, st, spheres5, materials8, triangles10, p, a.scene)) return rc;
+    fill_const<T>(a.rc, camera12, p, rows, slots);
+    a.L = (P4 *)c.L.p;
+    a.counts = (uint32_t *)c.counts.p;
+    a.stats = (spira::Stats *)c.stats.p;
+
+    const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + spira::kCompactScratchBytes;
+    const uint32_t n_pass = (p->spp + slots - 1) / slots;
+    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", 8);
+
+    T *d_hdr = out_hdr, *d_img = out_img;
+    if (!out_on_device) {
+        size_t plane3 = 3 * tile_pixels * sizeof(T);
+        if (int rc = c.out_tmp.ensure(2 * plane3)) return rc;
+        d_hdr = out_hdr ? (T *)c.out_tmp.p : nullptr;
+        d_img = out_img ? (T *)((char *)c.out_tmp.p + plane3) : nullptr;
+    }
+
+    size_t n_prof = 0;
+    if (profile) {
+        n_prof = (size_t)n_pass * std::max<uint32_t>(p->max_depth, 1) * 2;
+        if (int rc = profile_events(c, n_prof)) return rc;
+    }
+    c.ev_used = 0;
+
+    HIP_TRY(hipMemsetAsync(c.stats.p, 0, sizeof(spira::Stats), st));
+    HIP_TRY(hipEventRecord(c.ev_start, st));
+    uint64_t launches = 0;
+
+    if (p->max_depth == 0) {
+        HIP_TRY(hipMemsetAsync(c.accum.p, 0, tile_pixels * sizeof(P4), st));   // depth <= 0 -> Vec3(0,0,0), :330
+    } else {
+        for (uint32_t pass = 0; pass < n_pass; ++pass) {
+            const uint32_t k_eff = std::min(slots, p->spp - pass * slots);
+            const uint32_t n_first = (uint32_t)((uint64_t)k_eff * tile_pixels);
+            a.pass = pass;
+            a.n_first = n_first;
+            if (mega) {
+                uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
+                hipLaunchKernelGGL((spira::k_mega<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                ++launches;
+            } else {
+                HIP_TRY(hipMemsetAsync(c.counts.p, 0, (p->max_depth + 2) * sizeof(uint32_t), st));
+                const uint32_t ch = spira::kBlock * R;
+                uint32_t blocks = std::min<uint32_t>((n_first + ch - 1) / ch, max_blocks);
+                for (uint32_t b = 0; b < p->max_depth; ++b) {
+                    a.bounce = b;
+                    int qi = b & 1;      // bounce b writes queue qi, reads queue qi^1
+                    a.qout = {(P4 *)c.qA[qi].p, (P4 *)c.qB[qi].p, (P2 *)c.qC[qi].p};
+                    a.qin = {(P4 *)c.qA[qi ^ 1].p, (P4 *)c.qB[qi ^ 1].p, (P2 *)c.qC[qi ^ 1].p};
+                    if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
+                    if (b == 0) launch_bounce<T, true>(R, dim3(blocks), lds, st, a);
+                    else launch_bounce<T, false>(R, dim3(blocks), lds, st, a);
+                    if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
+                    ++launches;
+                }
+            }
+            uint32_t rblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
+            hipLaunchKernelGGL((spira::k_resolve<T>), dim3(rblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const P4 *)c.L.p,
+                               (uint32_t)tile_pixels, k_eff, pass == 0 ? 1 : 0);
+            ++launches;
+        }
+    }
+    {
+        uint32_t fblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
+        hipLaunchKernelGGL((spira::k_finalize<T>), dim3(fblocks), dim3(spira::kBlock), 0, st, (const P4 *)c.accum.p, (uint32_t)tile_pixels,
+                           p->spp, p->flags & SPIRA_POST_MASK, d_hdr, d_img);
+        ++launches;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c.ev_stop, st));
+    HIP_TRY(hipMemcpyAsync(c.h_stats, c.stats.p, sizeof(spira::Stats), hipMemcpyDeviceToHost, st));
+
+    c.last = spira_counters{};
+    c.last.samples = (uint64_t)p->spp * tile_pixels;
+    c.last.passes = p->max_depth ? n_pass : 0;
+    c.last.launches = launches;
+    c.last.bounce_launches = (mega || !p->max_depth) ? 0 : (uint64_t)n_pass * p->max_depth;
+    c.last_valid = true;
+    c.last_pending = true;
+    c.last_stream = st;
+
+    if (!out_on_device) {
+        size_t plane3 = 3 * tile_pixels * sizeof(T);
+        if (out_hdr) HIP_TRY(hipMemcpyAsync(out_hdr, d_hdr, plane3, hipMemcpyDeviceToHost, st));
+        if (out_img) HIP_TRY(hipMemcpyAsync(out_img, d_img, plane3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+template <class T>
+int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
+               uint32_t n_paths, const uint32_t *ijs, int *prims, T *ts, T *dirs, T *radiance) {
+    uint32_t rows = 0;
+    if (int rc = validate<T>(spheres5, materials8, triangles10, camera12, p, &rows)) return rc;
+    if (!n_paths || !ijs || !prims || !ts || !dirs || !radiance) return fail(SPIRA_E_INVALID, "NULL argument");
+    if (p->max_depth < 1) return fail(SPIRA_E_INVALID, "max_depth must be >= 1");
+    for (uint32_t k = 0; k < n_paths; ++k)
+        if (ijs[3 * k] < 1 || ijs[3 * k] > p->width || ijs[3 * k + 1] < 1 || ijs[3 * k + 1] > p->height || ijs[3 * k + 2] >= p->spp)
+            return fail(SPIRA_E_INVALID, "path (i, j, sample) out of range");
+    Ctx *cp = nullptr;
+    if (int rc = get_ctx(&cp)) return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::mutex> lock(c.mu);
+    hipStream_t st = c.stream;
+    spira::BounceArgs<T> a{};
+    if (int rc = upload_scene<T>(c, st, spheres5, materials8, triangles10, p, a.scene)) return rc;
+    fill_const<T>(a.rc, camera12, p, rows, 1);
+    size_t nseg = (size_t)n_paths * p->max_depth;
+    size_t b_ij = ((size_t)n_paths * 3 * sizeof(uint32_t) + 255) & ~(size_t)255;
+    size_t b_pr = (nseg * sizeof(int) + 255) & ~(size_t)255;
+    size_t b_ts = (nseg * sizeof(T) + 255) & ~(size_t)255;
+    size_t b_di = (nseg * 3 * sizeof(T) + 255) & ~(size_t)255;
+    size_t b_ra = ((size_t)n_paths * 3 * sizeof(T) + 255) & ~(size_t)255;
+    if (int rc = c.trace.ensure(b_ij + b_pr + b_ts + b_di + b_ra)) return rc;
+    char *base = (char *)c.trace.p;
+    uint32_t *d_ij = (uint32_t *)base;
+    int *d_pr = (int *)(base + b_ij);
+    T *d_ts = (T *)(base + b_ij + b_pr);
+    T *d_di = (T *)(base + b_ij + b_pr + b_ts);
+    T *d_ra = (T *)(base + b_ij + b_pr + b_ts + b_di);
+    HIP_TRY(hipMemcpyAsync(d_ij, ijs, (size_t)n_paths * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_ts, 0, b_ts + b_di, st));
+    const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + spira::kCompactScratchBytes;
+    hipLaunchKernelGGL((spira::k_trace<T>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(prims, d_pr, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ts, d_ts, nseg * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(dirs, d_di, nseg * 3 * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(radiance, d_ra, (size_t)n_paths * 3 * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+// Camera constructor arithmetic, host side.  Statement order of
+// examples/julia-raytracer.jl:280-291 == src/spira-metal-optimized.jl:332-345 (focus_dist = 1).
+template <class T> struct HV { T x, y, z; };
+template <class T> HV<T> hsub(HV<T> a, HV<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> HV<T> hscale(HV<T> a, T s) { return {a.x * s, a.y * s, a.z * s}; }
+template <class T> HV<T> hdiv(HV<T> a, T s) { return {a.x / s, a.y / s, a.z / s}; }
+template <class T> T hdot(HV<T> a, HV<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class T> HV<T> hcross(HV<T> a, HV<T> b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+template <class T> HV<T> hnorm(HV<T> a) { return hdiv(a, (T)std::sqrt(hdot(a, a))); }
+
+template <class T>
+void camera_impl(const T *position, const T *look_at, const T *up, T fov_deg, T aspect, T focus_dist, T *out12) {
+    HV<T> pos{position[0], position[1], position[2]}, la{look_at[0], look_at[1], look_at[2]}, vup{up[0], up[1], up[2]};
+    T theta = fov_deg * ((T)3.14159265358979323846 / (T)180);     // deg2rad(z) = z * (oftype(z, pi) / 180)
+    T h = std::tan(theta / 2);
+    T vh = (T)2.0 * h;
+    T vw = aspect * vh;
+    HV<T> w = hnorm(hsub(pos, la));
+    HV<T> u = hnorm(hcross(vup, w));
+    HV<T> v = hcross(w, u);
+    HV<T> hor = hscale(u, focus_dist * vw);
+    HV<T> ver = hscale(v, focus_dist * vh);
+    HV<T> llc = hsub(hsub(hsub(pos, hdiv(hor, (T)2)), hdiv(ver, (T)2)), hscale(w, focus_dist));
+    T o[12] = {pos.x, pos.y, pos.z, llc.x, llc.y, llc.z, hor.x, hor.y, hor.z, ver.x, ver.y, ver.z};
+    std::memcpy(out12, o, sizeof o);
+}
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" {
+
+int spira_abi_version(void) { return SPIRA_ABI_VERSION; }
+const char *spira_last_error(void) { return tl_err.c_str(); }
+
+int spira_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { tl_err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return 0; }
+    return n;
+}
+
+int spira_set_device(int device) {
+    int n = spira_device_count();
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail(SPIRA_E_INVALID, "device index out of range");
+    tl_device = device;
+    return 0;
+}
+
+int spira_get_counters(spira_counters *out) {
+    if (!out) return fail(SPIRA_E_INVALID, "out is NULL");
+    Ctx *cp = nullptr;
+    if (int rc = get_ctx(&cp)) return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (!c.last_valid) return fail(SPIRA_E_INVALID, "no render has run on this device");
+    if (c.last_pending) {
+        HIP_TRY(hipEventSynchronize(c.ev_stop));
+        HIP_TRY(hipStreamSynchronize(c.last_stream));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c.ev_start, c.ev_stop));
+        c.last.kernel_ms = ms;
+        c.last.segments = c.h_stats->segments;
+        c.last.rays_enqueued = c.h_stats->rays_enqueued;
+        c.last.radiance_rmw = c.h_stats->radiance_rmw;
+        double bms = 0;
+        for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
+            float m = 0;
+            HIP_TRY(hipEventElapsedTime(&m, c.ev_pool[i], c.ev_pool[i + 1]));
+            bms += m;
+        }
+        c.last.bounce_kernel_ms = bms;
+        c.last_pending = false;
+    }
+    *out = c.last;
+    return 0;
+}
+
+void spira_shutdown(void) {
+    for (int d = 0; d < kMaxDevices; ++d) {
+        Ctx &c = g_ctx[d];
+        std::lock_guard<std::mutex> lock(c.mu);
+        if (!c.init) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); }
+        c.L.release(); c.accum.release(); c.counts.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release();
+        for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
+        c.ev_pool.clear();
+        (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop);
+        (void)hipHostFree(c.h_stats);
+        (void)hipStreamDestroy(c.stream);
+        c.init = false; c.last_valid = false;
+    }
+}
+
+int spira_camera_lookat_f32(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov_deg, float aspect_ratio,
+                            float out12[12]) {
+    if (!lookfrom || !lookat || !vup || !out12) return fail(SPIRA_E_INVALID, "NULL argument");
+    camera_impl<float>(lookfrom, lookat, vup, vfov_deg, aspect_ratio, 1.0f, out12);
+    return 0;
+}
+int spira_camera_lookat_f64(const double position[3], const double look_at[3], const double up[3], double fov_deg, double aspect_ratio,
+                            double focus_dist, double out12[12]) {
+    if (!position || !look_at || !up || !out12) return fail(SPIRA_E_INVALID, "NULL argument");
+    camera_impl<double>(position, look_at, up, fov_deg, aspect_ratio, focus_dist, out12);
+    return 0;
+}
+
+int spira_render_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, float *out_hdr, float *out_img) {
+    return render_impl<float>(s, m, t, cam, p, out_hdr, out_img, false, nullptr);
+}
+int spira_render_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, double *out_hdr, double *out_img) {
+    return render_impl<double>(s, m, t, cam, p, out_hdr, out_img, false, nullptr);
+}
+int spira_render_device_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, float *d_hdr,
+                            float *d_img, void *stream) {
+    return render_impl<float>(s, m, t, cam, p, d_hdr, d_img, true, stream);
+}
+int spira_render_device_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, double *d_hdr,
+                            double *d_img, void *stream) {
+    return render_impl<double>(s, m, t, cam, p, d_hdr, d_img, true, stream);
+}
+
+int spira_trace_paths_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t n_paths,
+                          const uint32_t *ijs, int *prims, float *ts, float *dirs, float *radiance) {
+    return trace_impl<float>(s, m, t, cam, p, n_paths, ijs, prims, ts, dirs, radiance);
+}
+int spira_trace_paths_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t n_paths,
+                          const uint32_t *ijs, int *prims, double *ts, double *dirs, double *radiance) {
+    return trace_impl<double>(s, m, t, cam, p, n_paths, ijs, prims, ts, dirs, radiance);
+}
+
+int spira_tonemap_f32(float *values, uint64_t n, uint32_t post) {
+    if (!values && n) return fail(SPIRA_E_INVALID, "values is NULL");
+    post &= SPIRA_POST_MASK;
+    for (uint64_t i = 0; i < n; ++i) values[i] = spira::post1<float>(values[i], post);
+    return 0;
+}
+
+uint32_t spira_stripe_rows(uint32_t height, uint32_t stripe_h, uint32_t stripe_count, uint32_t stripe_rank) {
+    if (stripe_count == 0 || stripe_rank >= stripe_count) return 0;
+    return stripe_rows(height, stripe_h, stripe_count, stripe_rank);
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+/*
+ * spira_oracle_impl.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's path-trace integrator, included twice by spira_oracle.c:
+ * once with REAL = double (the precision of examples/julia-raytracer.jl) and once with
+ * REAL = float (same statements, Float32 arithmetic: the "bit mirror" the f32 HIP kernels are
+ * compared with).  Line numbers cite /root/reference (jenkinsm13/julia-spira @ 2025-09-05).
+ *
+ * PARITY UNPINNED: the reference holds no golden vectors, known-answer tests or fixtures for
+ * this path (its only assertion is size(image) == (64,64), tests/bunny-test.jl:59), it cannot
+ * be executed in this pipeline (no Julia), and it never seeds its RNG, so its random stream is
+ * not reproducible.  This file follows the reference statement by statement in everything
+ * except the random stream, which is the build's own counter-based generator (oracle_rng3).
+ *
+ * Must be compiled with -ffp-contract=off: Julia does not fuse a*b+c, and the HIP kernels are
+ * built the same way, so geometry is comparable bit for bit.
+ */
+
+/* ---------------------------------------------------------------------------------------- */
+/* Vec3 and its operators: examples/julia-raytracer.jl:11-41                                  */
+typedef struct { REAL x, y, z; } SUF(V3);
+#define V3 SUF(V3)
+
+static inline V3 SUF(v3)(REAL x, REAL y, REAL z) { V3 r = { x, y, z }; return r; }
+static inline V3 SUF(add)(V3 a, V3 b) { return SUF(v3)(a.x + b.x, a.y + b.y, a.z + b.z); }   /* :21 */
+static inline V3 SUF(sub)(V3 a, V3 b) { return SUF(v3)(a.x - b.x, a.y - b.y, a.z - b.z); }   /* :22 */
+static inline V3 SUF(scale)(V3 a, REAL b) { return SUF(v3)(a.x * b, a.y * b, a.z * b); }     /* :23-24 */
+static inline V3 SUF(divs)(V3 a, REAL b) { return SUF(v3)(a.x / b, a.y / b, a.z / b); }      /* :25 */
+static inline REAL SUF(dot)(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }         /* :26 */
+static inline REAL SUF(length)(V3 a) { return SQRT(SUF(dot)(a, a)); }                          /* :27 */
+static inline V3 SUF(normalize)(V3 a) { return SUF(divs)(a, SUF(length)(a)); }                 /* :28 */
+static inline V3 SUF(mulv)(V3 a, V3 b) { return SUF(v3)(a.x * b.x, a.y * b.y, a.z * b.z); }   /* :32-34 */
+static inline V3 SUF(cross)(V3 a, V3 b) {                                                      /* :37-41 */
+    return SUF(v3)(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+/* Material: examples/julia-raytracer.jl:53-62 (fields of materials8: diffuse, emission,
+ * specular, roughness — the same eight floats as Material_jl src/spira-metal-optimized.jl:379-384) */
+typedef struct { V3 diffuse, emission; REAL specular, roughness; } SUF(Material);
+#define Material SUF(Material)
+
+/* HitRecord: examples/julia-raytracer.jl:65-71 (material kept as an index) */
+typedef struct { REAL t; V3 position, normal; int material; int hit; int prim; } SUF(HitRecord);
+#define HitRecord SUF(HitRecord)
+
+typedef struct { V3 origin, direction; } SUF(Ray);                                             /* :44-47 */
+#define Ray SUF(Ray)
+static inline V3 SUF(point_at)(Ray r, REAL t) { return SUF(add)(r.origin, SUF(scale)(r.direction, t)); } /* :50 */
+
+typedef struct {
+    const REAL *spheres5, *materials8, *triangles10;
+    uint32_t n_spheres, n_materials, n_triangles;
+    V3 cam_origin, cam_llc, cam_hor, cam_ver;
+    uint32_t sA, sB;          /* seed halves after oracle_seed_mix */
+    uint32_t max_depth;
+    uint32_t sem;
+} SUF(World);
+#define World SUF(World)
+
+static inline Material SUF(get_material)(const World *w, int idx1) {
+    const REAL *m = w->materials8 + 8 * (size_t)(idx1 - 1);
+    Material r;
+    r.diffuse = SUF(v3)(m[0], m[1], m[2]);
+    r.emission = SUF(v3)(m[3], m[4], m[5]);
+    r.specular = m[6];
+    r.roughness = m[7];
+    return r;
+}
+
+/* Ray-sphere: examples/julia-raytracer.jl:113-142 */
+static HitRecord SUF(hit_sphere)(const REAL *s5, Ray ray, REAL t_min, REAL t_max) {
+    HitRecord miss; memset(&miss, 0, sizeof miss);
+    V3 center = SUF(v3)(s5[0], s5[1], s5[2]);
+    REAL radius = s5[3];
+    V3 oc = SUF(sub)(ray.origin, center);                       /* :114 */
+    REAL a = SUF(dot)(ray.direction, ray.direction);            /* :115 */
+    REAL b = (REAL)2.0 * SUF(dot)(oc, ray.direction);           /* :116 */
+    REAL c = SUF(dot)(oc, oc) - radius * radius;                /* :117 */
+    REAL discriminant = b * b - (REAL)4 * a * c;                /* :118  (4*a)*c */
+    if (discriminant < 0) return miss;                          /* :120 */
+    REAL sqrtd = SQRT(discriminant);                            /* :125 */
+    REAL root1 = (-b - sqrtd) / ((REAL)2.0 * a);                /* :126 */
+    REAL root2 = (-b + sqrtd) / ((REAL)2.0 * a);                /* :127 */
+    if (root1 < t_min || root1 > t_max) {                       /* :130 */
+        root1 = root2;
+        if (root1 < t_min || root1 > t_max) return miss;        /* :132 */
+    }
+    HitRecord rec;
+    rec.t = root1;                                              /* :137 */
+    rec.position = SUF(point_at)(ray, rec.t);                   /* :138 */
+    rec.normal = SUF(normalize)(SUF(sub)(rec.position, center));/* :139 */
+    rec.material = (int)s5[4];
+    rec.hit = 1;
+    rec.prim = 0;
+    return rec;
+}
+
+/* Ray-triangle (Möller–Trumbore): examples/julia-raytracer.jl:145-187, normal :105-109 */
+static HitRecord SUF(hit_triangle)(const REAL *t10, Ray ray, REAL t_min, REAL t_max) {
+    HitRecord miss; memset(&miss, 0, sizeof miss);
+    V3 v0 = SUF(v3)(t10[0], t10[1], t10[2]);
+    V3 v1 = SUF(v3)(t10[3], t10[4], t10[5]);
+    V3 v2 = SUF(v3)(t10[6], t10[7], t10[8]);
+    V3 edge1 = SUF(sub)(v1, v0);                                /* :149 */
+    V3 edge2 = SUF(sub)(v2, v0);                                /* :150 */
+    V3 h = SUF(cross)(ray.direction, edge2);                    /* :153 */
+    REAL a = SUF(dot)(edge1, h);                                /* :154 */
+    if (FABS(a) < (REAL)1e-8) return miss;                      /* :157 */
+    REAL f = (REAL)1.0 / a;                                     /* :161 */
+    V3 s = SUF(sub)(ray.origin, v0);                            /* :162 */
+    REAL u = f * SUF(dot)(s, h);                                /* :163 */
+    if (u < (REAL)0.0 || u > (REAL)1.0) return miss;            /* :165 */
+    V3 q = SUF(cross)(s, edge1);                                /* :169 */
+    REAL v = f * SUF(dot)(ray.direction, q);                    /* :170 */
+    if (v < (REAL)0.0 || u + v > (REAL)1.0) return miss;        /* :172 */
+    REAL t = f * SUF(dot)(edge2, q);                            /* :177 */
+    if (t < t_min || t > t_max) return miss;                    /* :179 */
+    HitRecord rec;
+    rec.t = t;
+    rec.position = SUF(point_at)(ray, t);                       /* :183 */
+    rec.normal = SUF(normalize)(SUF(cross)(edge1, edge2));      /* :184 -> :105-109 */
+    rec.material = (int)t10[9];
+    rec.hit = 1;
+    rec.prim = 0;
+    return rec;
+}
+
+/* Closest-hit linear scan with a shrinking t_max: examples/julia-raytracer.jl:242-258
+ * (identical to HittableList :195-210).  Object order: spheres, then triangles, which is the
+ * order of create_scene() :605-629. */
+static HitRecord SUF(hit_world)(const World *w, Ray ray, REAL t_min, REAL t_max) {
+    REAL closest_so_far = t_max;                                /* :244 */
+    HitRecord result; memset(&result, 0, sizeof result);        /* :246 */
+    for (uint32_t i = 0; i < w->n_spheres; ++i) {               /* :248 */
+        HitRecord temp_rec = SUF(hit_sphere)(w->spheres5 + 5 * (size_t)i, ray, t_min, closest_so_far);
+        if (temp_rec.hit) {                                     /* :250 */
+            closest_so_far = temp_rec.t;                        /* :252 */
+            result = temp_rec;
+            result.prim = (int)i;
+        }
+    }
+    for (uint32_t i = 0; i < w->n_triangles; ++i) {
+        HitRecord temp_rec = SUF(hit_triangle)(w->triangles10 + 10 * (size_t)i, ray, t_min, closest_so_far);
+        if (temp_rec.hit) {
+            closest_so_far = temp_rec.t;
+            result = temp_rec;
+            result.prim = (int)(w->n_spheres + i);
+        }
+    }
+    return result;
+}
+
+/* get_ray: examples/julia-raytracer.jl:298-306 (lens ignored, :299-300).
+ * `llc + s*hor + t*ver - origin` parses as ((llc + s*hor) + t*ver) - origin. */
+static Ray SUF(get_ray)(const World *w, REAL s, REAL t) {
+    V3 origin = w->cam_origin;                                  /* :302 (offset = 0) */
+    V3 d = SUF(sub)(SUF(add)(SUF(add)(w->cam_llc, SUF(scale)(w->cam_hor, s)), SUF(scale)(w->cam_ver, t)), origin);
+    Ray r; r.origin = origin; r.direction = SUF(normalize)(d);  /* :303 */
+    return r;
+}
+
+/* The build's counter-based RNG (DESIGN.md "RNG").  One call = one "try": three uniforms that
+ * are exact multiples of 2^-21, identical in Float32 and Float64. */
+typedef struct { uint32_t hA, hB; } SUF(RngKey);
+#define RngKey SUF(RngKey)
+
+static inline RngKey SUF(rng_key)(const World *w, uint32_t pixel, uint32_t sample, uint32_t bounce) {
+    uint32_t sb = (sample << 8) | bounce;
+    RngKey k;
+    k.hA = oracle_mix32(oracle_mix32(w->sA + pixel) ^ sb);
+    k.hB = oracle_mix32(oracle_mix32(w->sB ^ pixel) + sb);
+    return k;
+}
+
+static inline void SUF(rng3)(RngKey k, uint32_t t, REAL *u0, REAL *u1, REAL *u2) {
+    uint32_t a = oracle_mix32((k.hA + t * 0x9E3779B9u) ^ ((k.hB << 16) | (k.hB >> 16)));
+    uint32_t b = oracle_mix32(a + k.hB);
+    *u0 = (REAL)(a >> 11) * (REAL)(1.0 / 2097152.0);
+    *u1 = (REAL)(b >> 11) * (REAL)(1.0 / 2097152.0);
+    *u2 = (REAL)(((a & 0x7FFu) << 10) | (b & 0x3FFu)) * (REAL)(1.0 / 2097152.0);
+}
+
+/* random_in_unit_sphere: examples/julia-raytracer.jl:309-316.  The reference loops forever;
+ * here tries are t = 1..ORACLE_MAX_TRIES (try 0 belongs to the pixel jitter), after which the
+ * zero vector is returned (probability (1-pi/6)^64 ~ 2e-21 per call; the kernels do the same). */
+static V3 SUF(random_in_unit_sphere)(RngKey k) {
+    for (uint32_t t = 1; t <= ORACLE_MAX_TRIES; ++t) {
+        REAL u0, u1, u2;
+        SUF(rng3)(k, t, &u0, &u1, &u2);
+        V3 p = SUF(sub)(SUF(scale)(SUF(v3)(u0, u1, u2), (REAL)2.0), SUF(v3)(1, 1, 1));  /* :311 */
+        if (SUF(dot)(p, p) < (REAL)1.0) return p;                                      /* :312 */
+    }
+    return SUF(v3)(0, 0, 0);
+}
+
+/* reflect: examples/julia-raytracer.jl:323-325.  `2 * dot(v,n) * n` = (2*dot(v,n)) * n */
+static inline V3 SUF(reflect)(V3 v, V3 n) {
+    return SUF(sub)(v, SUF(scale)(n, (REAL)2 * SUF(dot)(v, n)));
+}
+
+/* Optional per-segment trace of one path (tests compare geometry bit for bit). */
+typedef struct { int prim; REAL t; REAL dir[3]; } SUF(TraceSeg);
+#define TraceSeg SUF(TraceSeg)
+
+/* ray_color: examples/julia-raytracer.jl:328-367 (recursive, like the reference) */
+static V3 SUF(ray_color)(const World *w, Ray ray, int depth, uint32_t pixel, uint32_t sample,
+                         uint64_t *segments, TraceSeg *trace) {
+    if (depth <= 0) return SUF(v3)(0, 0, 0);                                      /* :330 */
+    uint32_t bounce = w->max_depth - (uint32_t)depth;
+    if (segments) ++*segments;
+    HitRecord rec = SUF(hit_world)(w, ray, (REAL)0.001, (REAL)INFINITY);          /* :335 */
+    if (trace) {
+        trace[bounce].prim = rec.hit ? rec.prim : -1;
+        trace[bounce].t = rec.hit ? rec.t : (REAL)0;
+        trace[bounce].dir[0] = ray.direction.x; trace[bounce].dir[1] = ray.direction.y; trace[bounce].dir[2] = ray.direction.z;
+    }
+    if (rec.hit) {                                                                /* :337 */
+        Material m = SUF(get_material)(w, rec.material);
+        V3 emitted = m.emission;                                                  /* :339 */
+        RngKey k = SUF(rng_key)(w, pixel, sample, bounce);
+        if (m.specular > (REAL)0.0) {                                             /* :342 */
+            V3 reflected = SUF(reflect)(ray.direction, rec.normal);               /* :344 */
+            if (m.roughness > (REAL)0.0)                                          /* :346 */
+                reflected = SUF(add)(reflected, SUF(scale)(SUF(random_in_unit_sphere)(k), m.roughness)); /* :347 */
+            Ray scattered; scattered.origin = rec.position;
+            scattered.direction = SUF(normalize)(reflected);                      /* :349 */
+            V3 specular_color = SUF(ray_color)(w, scattered, depth - 1, pixel, sample, segments, trace); /* :352 */
+            return SUF(add)(emitted, SUF(mulv)(SUF(scale)(specular_color, m.specular), m.diffuse));      /* :353 */
+        } else {
+            V3 target = SUF(add)(SUF(add)(rec.position, rec.normal), SUF(random_in_unit_sphere)(k));    /* :356 */
+            Ray scattered; scattered.origin = rec.position;
+            scattered.direction = SUF(normalize)(SUF(sub)(target, rec.position)); /* :357 */
+            V3 in = SUF(ray_color)(w, scattered, depth - 1, pixel, sample, segments, trace);
+            return SUF(add)(emitted, SUF(mulv)(SUF(scale)(in, (REAL)0.5), m.diffuse));                  /* :360 */
+        }
+    }
+    REAL t = (REAL)0.5 * (ray.direction.y + (REAL)1.0);                           /* :365 */
+    return SUF(add)(SUF(scale)(SUF(v3)(1.0, 1.0, 1.0), (REAL)1.0 - t),
+                    SUF(scale)(SUF(v3)((REAL)0.5, (REAL)0.7, (REAL)1.0), t));     /* :366 */
+}
+
+/* to_acescg: examples/julia-raytracer.jl:370-384 (clamp, no gamma) */
+static inline REAL SUF(aces1)(REAL x) {
+    const REAL a = (REAL)2.51, b = (REAL)0.03, c = (REAL)2.43, d = (REAL)0.59, e = (REAL)0.14;
+    REAL v = (x * (a * x + b)) / (x * (c * x + d) + e);                           /* :379 */
+    return v < 0 ? 0 : (v > 1 ? 1 : v);
+}
+
+static inline REAL SUF(post1)(REAL x, uint32_t post) {
+    switch (post) {
+    case SPIRA_POST_ACES: return SUF(aces1)(x);
+    case SPIRA_POST_ACES_GAMMA: return SQRT(SUF(aces1)(x));                       /* src/spira-metal-optimized.jl:1136-1142 */
+    case SPIRA_POST_CLAMP_GAMMA: { REAL v = x < 0 ? 0 : (x > 1 ? 1 : x); return SQRT(v); } /* :1441-1442 */
+    default: return x;
+    }
+}
+
+static void SUF(world_init)(World *w, const REAL *spheres5, const REAL *materials8, const REAL *triangles10,
+                            const REAL *camera12, const spira_params *p) {
+    w->spheres5 = spheres5; w->materials8 = materials8; w->triangles10 = triangles10;
+    w->n_spheres = p->n_spheres; w->n_materials = p->n_materials; w->n_triangles = triangles10 ? p->n_triangles : 0;
+    w->cam_origin = SUF(v3)(camera12[0], camera12[1], camera12[2]);
+    w->cam_llc = SUF(v3)(camera12[3], camera12[4], camera12[5]);
+    w->cam_hor = SUF(v3)(camera12[6], camera12[7], camera12[8]);
+    w->cam_ver = SUF(v3)(camera12[9], camera12[10], camera12[11]);
+    oracle_seed_mix(p->seed, &w->sA, &w->sB);
+    w->max_depth = p->max_depth;
+    w->sem = p->flags & SPIRA_SEM_MASK;
+}
+
+/* One sample of one pixel: the body of the sample loop, examples/julia-raytracer.jl:398-401.
+ * i, j are the reference's 1-based loop indices; pixel id = (j-1)*W + (i-1). */
+static V3 SUF(sample_pixel)(const World *w, const spira_params *p, uint32_t i, uint32_t j, uint32_t sample,
+                            uint64_t *segments, TraceSeg *trace) {
+    uint32_t pixel = (j - 1) * p->width + (i - 1);
+    REAL xi_u, xi_v, unused;
+    SUF(rng3)(SUF(rng_key)(w, pixel, sample, 0), 0, &xi_u, &xi_v, &unused);
+    REAL u = ((REAL)(i - 1) + xi_u) / (REAL)(p->width - 1);                       /* :398 */
+    REAL v = ((REAL)(j - 1) + xi_v) / (REAL)(p->height - 1);                      /* :399 */
+    Ray ray = SUF(get_ray)(w, u, v);                                              /* :400 */
+    return SUF(ray_color)(w, ray, (int)p->max_depth, pixel, sample, segments, trace); /* :401 */
+}
+
+/* render: examples/julia-raytracer.jl:387-421.  out_hdr / out_img are planar (3 planes of
+ * rows*width), row order and tiling as documented in include/spira_hip.h. */
+int SUF(oracle_render)(const REAL *spheres5, const REAL *materials8, const REAL *triangles10,
+                       const REAL *camera12, const spira_params *p, REAL *out_hdr, REAL *out_img,
+                       int n_threads, uint64_t *segments_out) {
+    if (!spheres5 || !materials8 || !camera12 || !p) return -1;
+    if ((p->flags & SPIRA_SEM_MASK) != SPIRA_SEM_A) return -5;
+    World w; SUF(world_init)(&w, spheres5, materials8, triangles10, camera12, p);
+    uint32_t W = p->width, H = p->height;
+    uint32_t rows = p->rows ? p->rows : H;
+    size_t plane = (size_t)rows * W;
+    uint32_t post = p->flags & SPIRA_POST_MASK;
+    uint64_t segments = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : segments)
+#endif
+    for (uint32_t r = 0; r < rows; ++r) {
+        /* local output row r -> global output row y (row 0 = top unless ROWS_BOTTOM_UP) */
+        uint32_t y = p->rows ? oracle_global_row(p, r) : r;
+        /* the reference stores loop row j at hdr_data[height-j+1, i] (:408): top row = j = H */
+        uint32_t j = (p->flags & SPIRA_ROWS_BOTTOM_UP) ? y + 1 : H - y;
+        for (uint32_t i = 1; i <= W; ++i) {                                       /* :393 */
+            V3 color = SUF(v3)(0, 0, 0);                                          /* :394 */
+            for (uint32_t s = 0; s < p->spp; ++s)                                 /* :397 */
+                color = SUF(add)(color, SUF(sample_pixel)(&w, p, i, j, s, &segments, NULL)); /* :401 */
+            color = SUF(divs)(color, (REAL)p->spp);                               /* :405 */
+            size_t o = (size_t)r * W + (i - 1);
+            if (out_hdr) { out_hdr[o] = color.x; out_hdr[plane + o] = color.y; out_hdr[2 * plane + o] = color.z; } /* :408 */
+            if (out_img) {                                                        /* :411 */
+                out_img[o] = SUF(post1)(color.x, post);
+                out_img[plane + o] = SUF(post1)(color.y, post);
+                out_img[2 * plane + o] = SUF(post1)(color.z, post);
+            }
+        }
+    }
+    if (segments_out) *segments_out = segments;
+    return 0;
+}
+
+/* Trace one path: per-segment primitive index (-1 = miss), t and ray direction, plus the
+ * sample's radiance.  Returns the number of segments traced. */
+int SUF(oracle_trace_path)(const REAL *spheres5, const REAL *materials8, const REAL *triangles10,
+                           const REAL *camera12, const spira_params *p, uint32_t i, uint32_t j, uint32_t sample,
+                           int *prims, REAL *ts, REAL *dirs3, REAL *radiance3) {
+    World w; SUF(world_init)(&w, spheres5, materials8, triangles10, camera12, p);
+    TraceSeg tr[256];
+    for (uint32_t b = 0; b < 256; ++b) { tr[b].prim = -2; tr[b].t = 0; tr[b].dir[0] = tr[b].dir[1] = tr[b].dir[2] = 0; }
+    uint64_t segs = 0;
+    V3 c = SUF(sample_pixel)(&w, p, i, j, sample, &segs, tr);
+    for (uint32_t b = 0; b < p->max_depth; ++b) {
+        prims[b] = tr[b].prim; ts[b] = tr[b].t;
+        dirs3[3 * b] = tr[b].dir[0]; dirs3[3 * b + 1] = tr[b].dir[1]; dirs3[3 * b + 2] = tr[b].dir[2];
+    }
+    radiance3[0] = c.x; radiance3[1] = c.y; radiance3[2] = c.z;
+    return (int)segs;
+}
+
+/* Camera constructor: examples/julia-raytracer.jl:271-294 (and, with focus_dist = 1 and
+ * Float32, src/spira-metal-optimized.jl:331-347).  out12 = origin, llc, horizontal, vertical. */
+void SUF(oracle_camera)(const REAL *position, const REAL *look_at, const REAL *up, REAL fov_deg,
+                        REAL aspect_ratio, REAL focus_dist, REAL *out12) {
+    V3 pos = SUF(v3)(position[0], position[1], position[2]);
+    V3 la = SUF(v3)(look_at[0], look_at[1], look_at[2]);
+    V3 vup = SUF(v3)(up[0], up[1], up[2]);
+    REAL theta = DEG2RAD(fov_deg);                                               /* :280 */
+    REAL h = TAN(theta / 2);                                                     /* :281 */
+    REAL viewport_height = (REAL)2.0 * h;                                        /* :282 */
+    REAL viewport_width = aspect_ratio * viewport_height;                        /* :283 */
+    V3 w = SUF(normalize)(SUF(sub)(pos, la));                                    /* :285 */
+    V3 u = SUF(normalize)(SUF(cross)(vup, w));                                   /* :286 */
+    V3 v = SUF(cross)(w, u);                                                     /* :287 */
+    V3 horizontal = SUF(scale)(u, focus_dist * viewport_width);                  /* :289 */
+    V3 vertical = SUF(scale)(v, focus_dist * viewport_height);                   /* :290 */
+    V3 llc = SUF(sub)(SUF(sub)(SUF(sub)(pos, SUF(divs)(horizontal, 2)), SUF(divs)(vertical, 2)),
+                      SUF(scale)(w, focus_dist));                                /* :291 */
+    out12[0] = pos.x; out12[1] = pos.y; out12[2] = pos.z;
+    out12[3] = llc.x; out12[4] = llc.y; out12[5] = llc.z;
+    out12[6] = horizontal.x; out12[7] = horizontal.y; out12[8] = horizontal.z;
+    out12[9] = vertical.x; out12[10] = vertical.y; out12[11] = vertical.z;
+}
+
+/* Thin wrappers for known-answer tests */
+int SUF(oracle_hit_sphere)(const REAL *s5, const REAL *o3, const REAL *d3, REAL t_min, REAL t_max, REAL *t, REAL *n3) {
+    Ray r; r.origin = SUF(v3)(o3[0], o3[1], o3[2]); r.direction = SUF(v3)(d3[0], d3[1], d3[2]);
+    HitRecord h = SUF(hit_sphere)(s5, r, t_min, t_max);
+    if (h.hit) { *t = h.t; n3[0] = h.normal.x; n3[1] = h.normal.y; n3[2] = h.normal.z; }
+    return h.hit;
+}
+int SUF(oracle_hit_triangle)(const REAL *t10, const REAL *o3, const REAL *d3, REAL t_min, REAL t_max, REAL *t, REAL *n3) {
+    Ray r; r.origin = SUF(v3)(o3[0], o3[1], o3[2]); r.direction = SUF(v3)(d3[0], d3[1], d3[2]);
+    HitRecord h = SUF(hit_triangle)(t10, r, t_min, t_max);
+    if (h.hit) { *t = h.t; n3[0] = h.normal.x; n3[1] = h.normal.y; n3[2] = h.normal.z; }
+    return h.hit;
+}
+void SUF(oracle_sky)(const REAL *d3, REAL *rgb) {
+    World w; memset(&w, 0, sizeof w); w.max_depth = 1;
+    Ray r; r.origin = SUF(v3)(0, 0, 0); r.direction = SUF(v3)(d3[0], d3[1], d3[2]);
+    V3 c = SUF(ray_color)(&w, r, 1, 0, 0, NULL, NULL);
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+REAL SUF(oracle_post)(REAL x, uint32_t post) { return SUF(post1)(x, post); }
+void SUF(oracle_rng_try)(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t t, REAL *u3) {
+    World w; memset(&w, 0, sizeof w); oracle_seed_mix(seed, &w.sA, &w.sB);
+    SUF(rng3)(SUF(rng_key)(&w, pixel, sample, bounce), t, &u3[0], &u3[1], &u3[2]);
+}
+
+#undef V3
+#undef Material
+#undef HitRecord
+#undef Ray
+#undef World
+#undef RngKey
+#undef TraceSeg

@@ -1,0 +1,50 @@
+"""Regenerates tests/golden/*.json from the CPU oracle (oracle/spira_oracle.c).
+
+These fixtures are outputs of THIS build's oracle on seeded inputs — regression pins shared by
+the CPU tests (oracle stays what it was) and the GPU tests (HIP path == oracle).  They are not
+reference outputs: the reference (Julia) cannot run in this pipeline and holds no vectors.
+Run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, "julia-spira_amd"), os.path.join(ROOT, "oracle")]
+import oracle_py as O  # noqa: E402
+from spira_hip import scenes  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    rng = np.random.default_rng(20261004)
+    # config 1: S2, 320x180 spp4 depth4
+    s = scenes.scene_s2()
+    seed = scenes.seed_for(1)
+    p = O.make_params(320, 180, 4, 4, 5, 6, 1, seed=seed)
+    pixels = [[int(rng.integers(0, 180)), int(rng.integers(0, 320))] for _ in range(256)]
+    out = {"config": "c1: S2 (examples/julia-raytracer.jl create_scene) 320x180 spp=4 depth=4", "seed": seed, "pixels": pixels}
+    for prec in ("f64", "f32"):
+        hdr, _, seg = O.render(s["spheres5"], s["materials8"], s["triangles10"], s["camera12"], p, prec)
+        out[prec] = {"segments": int(seg), "values": [[float(v) for v in hdr[:, y, x]] for y, x in pixels],
+                     "mean": [float(hdr[c].astype(np.float64).mean()) for c in range(3)]}
+    json.dump(out, open(os.path.join(HERE, "c1_s2_320x180_spp4_d4.json"), "w"), indent=0)
+
+    # config 2 (reduced for CPU time): S1, 160x90 spp16 depth4, Float32 scene values
+    s = scenes.scene_s1()
+    seed = scenes.seed_for(2)
+    p = O.make_params(160, 90, 16, 4, 5, 5, 0, seed=seed)
+    pixels = [[int(rng.integers(0, 90)), int(rng.integers(0, 160))] for _ in range(256)]
+    out = {"config": "c2 (quarter size): S1 (src create_scene) 160x90 spp=16 depth=4", "seed": seed, "pixels": pixels}
+    for prec in ("f64", "f32"):
+        hdr, _, seg = O.render(s["spheres5"], s["materials8"], None, s["camera12"], p, prec)
+        out[prec] = {"segments": int(seg), "values": [[float(v) for v in hdr[:, y, x]] for y, x in pixels],
+                     "mean": [float(hdr[c].astype(np.float64).mean()) for c in range(3)]}
+    json.dump(out, open(os.path.join(HERE, "c2_s1_160x90_spp16_d4.json"), "w"), indent=0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol include/spira_hip.h declares,
+its host-side arithmetic agrees with the oracle, argument validation works, and — with no GPU —
+render calls fail loudly (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from spira_hip import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header(binding):
+    hdr = open(os.path.join(ROOT, "include", "spira_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(spira_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = binding.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libspira_hip.so does not export %s" % name
+    assert declared == set(binding.EXPORTS)
+    assert lib.spira_abi_version() == 1
+
+
+def test_struct_sizes(binding):
+    assert C.sizeof(binding.Params) == 64
+    assert C.sizeof(binding.Counters) == 9 * 8
+
+
+def test_library_is_gfx950_only():
+    import subprocess
+    from spira_hip import _binding
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", "--input=" + _binding.LIB_PATH],
+                         capture_output=True, text=True)
+    if out.returncode == 0 and out.stdout.strip():
+        targets = [t for t in out.stdout.split() if "amdgcn" in t]
+        assert targets and all("gfx950" in t for t in targets), targets
+    else:   # fall back to scanning the fat binary for arch strings
+        blob = open(_binding.LIB_PATH, "rb").read()
+        assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_camera_matches_oracle(binding, oracle, prec):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        pos, la = rng.normal(size=3) * 3, rng.normal(size=3)
+        fov, asp = float(rng.uniform(20, 100)), float(rng.uniform(0.5, 2.5))
+        a = binding.camera_lookat(pos, la, [0, 1, 0], fov, asp, 1.0, prec)
+        b = oracle.camera(pos, la, [0, 1, 0], fov, asp, 1.0, prec)
+        assert np.array_equal(a, b)
+    c = binding.camera_lookat([0, 1, 3], [0, 0, 0], [0, 1, 0], 40.0, np.float32(16 / 9), prec="f32")
+    assert np.allclose(c[3:6], [-0.6470582, 0.3384798, 2.1664143], atol=2e-6)   # SURVEY G7 KAT
+
+
+def test_tonemap_matches_oracle(binding, oracle):
+    x = np.concatenate([np.linspace(-1, 8, 500), [0.18, 1.0, 4.0]]).astype(np.float32)
+    for post in (0x000, 0x100, 0x200, 0x300):
+        got = binding.tonemap(x, post)
+        want = np.array([oracle.post(float(v), post, "f32") for v in x], dtype=np.float32)
+        assert np.array_equal(got, want)
+
+
+def test_stripe_rows(binding):
+    from spira_hip import distributed as D
+    for h, sh, n in [(1080, 8, 8), (1080, 8, 3), (27, 4, 3), (17, 5, 4), (64, 64, 2)]:
+        tot = 0
+        for r in range(n):
+            rows = binding.stripe_rows(h, sh, n, r)
+            assert rows == len(D.rows_of_rank(h, n, r, sh))
+            tot += rows
+        assert tot == h
+    assert binding.stripe_rows(100, 8, 0, 0) == 0 and binding.stripe_rows(100, 8, 2, 2) == 0
+
+
+def test_validation_errors(binding):
+    s = scenes.scene_s1()
+    sp, ma, cam = s["spheres5"], s["materials8"], s["camera12"]
+
+    def rc(params, spheres=sp, mats=ma):
+        with pytest.raises(binding.SpiraError) as e:
+            binding.render(spheres, mats, None, cam, params)
+        return str(e.value)
+    assert "error -1" in rc(binding.make_params(1, 10, 1, 1, 5, 5))                      # width < 2
+    assert "error -4" in rc(binding.make_params(8, 8, 0, 1, 5, 5))                       # spp = 0
+    assert "error -4" in rc(binding.make_params(8, 8, 1, 256, 5, 5))                     # depth > 255
+    assert "error -4" in rc(binding.make_params(8, 8, 1, 1, 2000, 5))                    # too many spheres
+    bad = sp.copy()
+    bad[2, 4] = 6
+    assert "error -1" in rc(binding.make_params(8, 8, 1, 1, 5, 5), spheres=bad)          # material index out of range
+    assert "error -5" in rc(binding.make_params(8, 8, 1, 1, 5, 5, flags=0x7))            # unknown semantics
+    assert "error -1" in rc(binding.make_params(8, 8, 1, 1, 5, 5, row0=4, rows=8))       # tile outside the image
+    assert "error -1" in rc(binding.make_params(8, 8, 1, 1, 5, 5, rows=3, stripe_h=2, stripe_count=2, stripe_rank=0))
+
+
+def test_no_gpu_means_loud_failure(binding):
+    """In the CPU container the product path must raise — never fall back to a CPU renderer."""
+    if binding.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    s = scenes.scene_s1()
+    with pytest.raises(binding.SpiraError) as e:
+        binding.render(s["spheres5"], s["materials8"], None, s["camera12"], binding.make_params(16, 9, 1, 2, 5, 5))
+    assert "error -2" in str(e.value)
+
+
+def test_mirror_api_surface(binding):
+    import spira_hip
+    from spira_hip import raytracer
+    for name in ["Scene", "Camera", "Ray", "Sphere", "Material", "render_hybrid_gpu", "render", "create_scene",
+                 "Point3", "Vec3", "Color"]:   # src/SPIRA.jl:11-13 + README.md:50-53
+        assert hasattr(spira_hip, name)
+    scene = spira_hip.create_scene()
+    sd, md = spira_hip.prepare_scene_data(scene)
+    s1 = scenes.scene_s1()
+    assert sd.dtype == np.float32 and np.array_equal(sd.reshape(-1, 5), s1["spheres5"].astype(np.float32))
+    assert np.array_equal(md.reshape(-1, 8), s1["materials8"].astype(np.float32))
+    cam = spira_hip.Camera(spira_hip.Point3(0, 1, 3), spira_hip.Point3(0, 0, 0), spira_hip.Vec3(0, 1, 0), 40.0, 16 / 9)
+    assert np.array_equal(cam.flat(), s1["camera12"].astype(np.float32))
+    r = spira_hip.Ray(spira_hip.Point3(0, 0, 0), spira_hip.Vec3(0, 3, 4))
+    assert np.allclose(r.direction, [0, 0.6, 0.8])
+    world, camera = raytracer.create_scene()
+    sp, ma, tr = raytracer.flatten_world(world)
+    s2 = scenes.scene_s2()
+    assert np.array_equal(sp, s2["spheres5"]) and np.array_equal(ma, s2["materials8"]) and np.array_equal(tr, s2["triangles10"])
+    assert np.array_equal(camera.flat(), s2["camera12"])
+    with pytest.raises(ValueError):
+        raytracer.flatten_world(raytracer.BoundingVolumeHierarchy(list(reversed(world.objects))))
+
+
+def test_png_writer(tmp_path):
+    import zlib
+    from spira_hip.png import save_png
+    img = np.zeros((4, 5, 3), dtype=np.float32)
+    img[1, 2] = [1.0, 0.5, 0.0]
+    path = tmp_path / "x.png"
+    save_png(str(path), img)
+    blob = path.read_bytes()
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n" and blob[12:16] == b"IHDR"
+    i = blob.index(b"IDAT")
+    n = int.from_bytes(blob[i - 4:i], "big")
+    raw = zlib.decompress(blob[i + 4:i + 4 + n])
+    assert len(raw) == 4 * (1 + 5 * 3) and raw[1 * 16 + 1 + 2 * 3:1 * 16 + 1 + 2 * 3 + 3] == bytes([255, 128, 0])
