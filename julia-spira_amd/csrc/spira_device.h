@@ -65,10 +65,10 @@ __device__ __forceinline__ RngKey rng_key(uint32_t sA, uint32_t sB, uint32_t pix
     k.hBr = (k.hB << 16) | (k.hB >> 16);
     return k;
 }
-template <class T> __device__ __forceinline__ void rng3(const RngKey &k, uint32_t t, T &u0, T &u1, T &u2) {
+template <class T>
+__device__ __forceinline__ void rng3(const RngKey &k, uint32_t t, T &u0, T &u1, T &u2, const T s = (T)(1.0 / 2097152.0)) {
     uint32_t a = mix32((k.hA + t * 0x9E3779B9u) ^ k.hBr);
     uint32_t b = mix32(a + k.hB);
-    const T s = (T)(1.0 / 2097152.0);
     u0 = (T)(a >> 11) * s;
     u1 = (T)(b >> 11) * s;
     u2 = (T)(((a & 0x7FFu) << 10) | (b & 0x3FFu)) * s;
@@ -139,7 +139,29 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
 }
 
 // ------------------------------------------------------------------ per-render constants
+// Division by a launch constant: Granlund-Montgomery round-up method, exact for every uint32 n and
+// d >= 1 (one v_mul_hi_u32 instead of the ~20-instruction udiv expansion; path_of runs per segment).
+struct FastDiv { uint32_t magic, sh1, sh2; };
+__host__ inline FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f;
+    uint32_t l = 0;
+    while (l < 32 && (1ull << l) < d) ++l;                       // l = ceil(log2 d)
+    f.magic = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l ? l - 1 : 0;
+    return f;
+}
+__host__ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv &f) {
+#ifdef __HIP_DEVICE_COMPILE__
+    uint32_t t = __umulhi(f.magic, n);
+#else
+    uint32_t t = (uint32_t)(((uint64_t)f.magic * n) >> 32);
+#endif
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 template <class T> struct RenderConst {
+    FastDiv fd_tile, fd_width, fd_stripe;   // tile_pixels, width, stripe_h
     Vec<T> cam_origin, cam_llc, cam_hor, cam_ver;
     uint32_t width, height;      // full image
     uint32_t spp, max_depth;
@@ -154,8 +176,11 @@ template <class T> struct RenderConst {
 
 // local output row -> reference loop row j (1-based, j = 1 is v = 0, the image bottom)
 template <class T> __device__ __forceinline__ uint32_t ref_row_j(const RenderConst<T> &rc, uint32_t lr) {
-    uint32_t y = rc.stripe_count > 1 ? ((lr / rc.stripe_h) * rc.stripe_count + rc.stripe_rank) * rc.stripe_h + (lr % rc.stripe_h)
-                                     : rc.row0 + lr;
+    uint32_t y = rc.row0 + lr;
+    if (rc.stripe_count > 1) {
+        const uint32_t sq = fastdiv(lr, rc.fd_stripe);           // lr / stripe_h
+        y = (sq * rc.stripe_count + rc.stripe_rank) * rc.stripe_h + (lr - sq * rc.stripe_h);
+    }
     return (rc.flags & 0x00001000u /*SPIRA_ROWS_BOTTOM_UP*/) ? y + 1 : rc.height - y;   // hdr_data[height-j+1, i], :408
 }
 
@@ -211,8 +236,8 @@ template <class T> __device__ __forceinline__ Vec<T> random_in_unit_sphere(const
     Vec<T> p = mk<T>(0, 0, 0);
     for (uint32_t t = 1; t <= kMaxTries; ++t) {
         T u0, u1, u2;
-        rng3<T>(k, t, u0, u1, u2);
-        Vec<T> q = mk<T>(u0, u1, u2) * (T)2.0 - mk<T>(1, 1, 1);     // :311
+        rng3<T>(k, t, u0, u1, u2, (T)(1.0 / 1048576.0));            // 2*u: the doubling of :311 is exact, fold it into the scale
+        Vec<T> q = mk<T>(u0, u1, u2) - mk<T>(1, 1, 1);              // :311
         if (dot(q, q) < (T)1.0) { p = q; break; }                   // :312
     }
     return p;
@@ -295,9 +320,9 @@ __device__ __forceinline__ void camera_ray(const RenderConst<T> &rc, uint32_t i,
 template <class T>
 __device__ __forceinline__ void path_of(const RenderConst<T> &rc, uint32_t q, uint32_t pass, uint32_t &i, uint32_t &j,
                                         uint32_t &pixel, uint32_t &sample) {
-    uint32_t slot = q / rc.tile_pixels;
+    uint32_t slot = fastdiv(q, rc.fd_tile);
     uint32_t pl = q - slot * rc.tile_pixels;
-    uint32_t lr = pl / rc.width;
+    uint32_t lr = fastdiv(pl, rc.fd_width);
     uint32_t lx = pl - lr * rc.width;
     j = ref_row_j(rc, lr);
     i = lx + 1;
@@ -339,13 +364,13 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
     uint32_t(*s_wave_cnt)[4] = reinterpret_cast<uint32_t(*)[4]>(
         lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles));   // [kBlock/64][4 >= R]
     uint32_t &s_base = s_wave_cnt[kBlock / 64][0];
-    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
     const RenderConst<T> &rc = a.rc;
-
+    constexpr uint32_t CH = kBlock * R;
     const uint32_t n_in = FIRST ? a.n_first : a.counts[a.bounce];
+    if (blockIdx.x * CH >= n_in) return;       // block-uniform: surplus blocks of a late bounce leave before staging
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
     const bool scatter = (a.bounce + 1 < rc.max_depth);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr uint32_t CH = kBlock * R;
     unsigned long long n_rmw = 0;
 
     for (uint32_t base = blockIdx.x * CH; base < n_in; base += gridDim.x * CH) {

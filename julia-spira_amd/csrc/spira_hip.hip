@@ -162,6 +162,23 @@ void fill_const(spira::RenderConst<T> &rc, const T *cam, const spira_params *p, 
     else { rc.row0 = p->row0; rc.stripe_h = p->stripe_h; rc.stripe_count = p->stripe_count; rc.stripe_rank = p->stripe_rank; }
     rc.tile_pixels = rows * p->width;
     rc.slots = slots;
+    rc.fd_tile = spira::fastdiv_make(rc.tile_pixels);
+    rc.fd_width = spira::fastdiv_make(rc.width);
+    rc.fd_stripe = spira::fastdiv_make(rc.stripe_h ? rc.stripe_h : 1);
+}
+
+// The magic-number division is exact by construction; verify it anyway on the values a render can see.
+bool fastdiv_selfcheck(uint32_t d, uint32_t n_max) {
+    const spira::FastDiv f = spira::fastdiv_make(d);
+    uint32_t probes[] = {0u, 1u, d - 1, d, d + 1, 2 * d - 1, 2 * d, n_max / 2, n_max - 1, n_max, 0x7FFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t n : probes)
+        if (spira::fastdiv(n, f) != n / d) return false;
+    uint32_t x = 0x12345u;
+    for (int i = 0; i < 512; ++i) {
+        x = spira::mix32(x + i);
+        if (spira::fastdiv(x, f) != x / d) return false;
+    }
+    return true;
 }
 
 // Upload the flat scene arrays into one device buffer; returns device pointers in `g`.
@@ -216,7 +233,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
 
     const uint32_t W = p->width;
     const uint64_t tile_pixels = (uint64_t)rows * W;
-    uint32_t target = p->batch_rays ? p->batch_rays : env_u32("SPIRA_BATCH_RAYS", 4u << 20);
+    uint32_t target = p->batch_rays ? p->batch_rays : env_u32("SPIRA_BATCH_RAYS", 64u << 20);
     uint64_t slots64 = std::max<uint64_t>(1, target / tile_pixels);
     slots64 = std::min<uint64_t>(slots64, p->spp);
     if (slots64 * tile_pixels > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "tile too large: rows*width must be < 2^31");
@@ -224,8 +241,8 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     const uint64_t batch = slots64 * tile_pixels;
     const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA;
     const bool profile = (p->flags & SPIRA_FLAG_PROFILE) != 0;
-    int R = (int)env_u32("SPIRA_R", 2);
-    if (R != 1 && R != 2 && R != 4) R = 2;
+    int R = (int)env_u32("SPIRA_R", 4);
+    if (R != 1 && R != 2 && R != 4) R = 4;
 
     // ---- workspaces (cached per device, grown on demand; sized for 288 GB HBM: no chunking of a pass)
     using P4 = spira::Pack4<T>;
@@ -244,6 +261,9 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     spira::BounceArgs<T> a{};
     if (int rc = upload_scene<T>(c, st, spheres5, materials8, triangles10, p, a.scene)) return rc;
     fill_const<T>(a.rc, camera12, p, rows, slots);
+    if (!fastdiv_selfcheck(a.rc.tile_pixels, (uint32_t)batch) || !fastdiv_selfcheck(a.rc.width, a.rc.tile_pixels) ||
+        !fastdiv_selfcheck(a.rc.stripe_h ? a.rc.stripe_h : 1, rows))
+        return fail(SPIRA_E_LIMIT, "internal: fast division self-check failed");
     a.L = (P4 *)c.L.p;
     a.counts = (uint32_t *)c.counts.p;
     a.stats = (spira::Stats *)c.stats.p;
