@@ -13,7 +13,7 @@ namespace spira {
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr uint32_t kMaxTries = 64;   // bounded rejection sampling (P(exhaust) ~ 2e-21)
-constexpr size_t kCompactScratchBytes = 96;   // [kBlock/64 + 1][4] uint32 behind the LDS scene
+constexpr size_t kCompactScratchBytes = 96;   // [kBlock/64][4] wave counts + control words, behind the LDS scene
 
 // ------------------------------------------------------------------ small vector algebra
 // Operation order mirrors Vec3 of examples/julia-raytracer.jl:11-41.
@@ -246,17 +246,24 @@ template <class T> __device__ __forceinline__ Vec<T> random_in_unit_sphere(const
 // ------------------------------------------------------------------ one path segment (semantics A)
 // ray_color, examples/julia-raytracer.jl:328-367, in iterative form:
 //   L += beta * emission ; beta *= specular*diffuse | 0.5*diffuse ; on a miss L += beta * sky.
+// A segment is split in two so that the random vector it needs (which depends only on the RNG key, not
+// on the geometry) can be produced by ANY lane of the workgroup between the halves:
+//   segment_front : intersection, radiance terms, throughput, everything of the scatter that does not
+//                   need the random vector (o becomes the hit point)
+//   segment_back  : new direction from the pending vector and random_in_unit_sphere()
+enum : uint32_t { kDead = 0, kDiffuse = 1, kSpecRough = 2, kMirror = 3 };
+template <class T> struct Pending { Vec<T> v; T rough; uint32_t kind; };   // v = pos + n (diffuse) | reflected (specular)
 struct SegInfo { int prim; bool alive; bool has_contrib; };
 
 template <class T>
-__device__ __forceinline__ SegInfo trace_segment(const SceneLds<T> &sc, const RenderConst<T> &rc, Vec<T> &o, Vec<T> &d,
-                                                 Vec<T> &beta, uint32_t pixel, uint32_t sample, uint32_t bounce,
-                                                 bool scatter, Vec<T> &contrib, T &t_out) {
+__device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &o, const Vec<T> d, Vec<T> &beta, bool scatter,
+                                                 Vec<T> &contrib, T &t_out, Pending<T> &pend) {
     SegInfo info;
     T t;
     int prim = closest_hit<T>(sc, o, d, (T)0.001, t);                        // :335
     info.prim = prim;
     t_out = prim >= 0 ? t : (T)0;
+    pend.kind = kDead; pend.rough = 0; pend.v = mk<T>(0, 0, 0);
     if (prim < 0) {                                                          // miss: sky, :365-366
         T ts = (T)0.5 * (d.y + (T)1.0);
         Vec<T> sky = mk<T>(1.0, 1.0, 1.0) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts;
@@ -284,22 +291,41 @@ __device__ __forceinline__ SegInfo trace_segment(const SceneLds<T> &sc, const Re
     contrib = mulv(beta, emission);                                          // emitted, :339
     info.alive = scatter;
     if (scatter) {
-        bool is_spec = specular > (T)0.0;                                    // :342
-        bool need_rnd = is_spec ? (roughness > (T)0.0) : true;               // :346 / :356
-        Vec<T> rnd = mk<T>(0, 0, 0);
-        if (need_rnd) rnd = random_in_unit_sphere<T>(rng_key(rc.sA, rc.sB, pixel, sample, bounce));
-        Vec<T> nd;
-        if (is_spec) {
-            Vec<T> reflected = d - n * ((T)2 * dot(d, n));                   // reflect, :323-325, :344
-            if (roughness > (T)0.0) reflected = reflected + rnd * roughness; // :347
-            nd = normalize(reflected);                                       // :349
+        if (specular > (T)0.0) {                                             // :342
+            pend.v = d - n * ((T)2 * dot(d, n));                             // reflect, :323-325, :344
+            pend.kind = roughness > (T)0.0 ? kSpecRough : kMirror;           // :346
+            pend.rough = roughness;
             beta = mulv(beta * specular, diffuse);                           // :353
         } else {
-            Vec<T> target = (pos + n) + rnd;                                 // :356
-            nd = normalize(target - pos);                                    // :357
+            pend.v = pos + n;                                                // first half of :356
+            pend.kind = kDiffuse;
             beta = mulv(beta * (T)0.5, diffuse);                             // :360
         }
-        o = pos; d = nd;
+        o = pos;
+    }
+    return info;
+}
+
+template <class T>
+__device__ __forceinline__ Vec<T> segment_back(const Vec<T> pos, const Pending<T> &pend, const Vec<T> rnd) {
+    if (pend.kind == kDiffuse) return normalize((pend.v + rnd) - pos);       // :356-357
+    Vec<T> reflected = pend.v;
+    if (pend.kind == kSpecRough) reflected = reflected + rnd * pend.rough;   // :347
+    return normalize(reflected);                                             // :349
+}
+
+// Whole segment by one lane (megakernel / trace kernels).
+template <class T>
+__device__ __forceinline__ SegInfo trace_segment(const SceneLds<T> &sc, const RenderConst<T> &rc, Vec<T> &o, Vec<T> &d,
+                                                 Vec<T> &beta, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                                                 bool scatter, Vec<T> &contrib, T &t_out) {
+    Pending<T> pend;
+    SegInfo info = segment_front<T>(sc, o, d, beta, scatter, contrib, t_out, pend);
+    if (info.alive) {
+        Vec<T> rnd = mk<T>(0, 0, 0);
+        if (pend.kind == kDiffuse || pend.kind == kSpecRough)
+            rnd = random_in_unit_sphere<T>(rng_key(rc.sA, rc.sB, pixel, sample, bounce));
+        d = segment_back<T>(o, pend, rnd);
     }
     return info;
 }
@@ -343,7 +369,10 @@ template <class T> struct BounceArgs {
     RenderConst<T> rc;
     RayQueue<T> qin, qout;
     Pack4<T> *L;                     // per-path radiance of the pass batch (slot-major), 16/32 B each
-    uint32_t *counts;                // counts[b] = rays entering bounce b (b >= 1)
+    const uint32_t *cnt_in;          // [G] rays waiting in each workgroup's region of qin (bounce >= 1)
+    uint32_t *cnt_out;               // [G] survivors this bounce leaves in each region of qout
+    uint32_t *blk_stats;             // [G][2] segments traced, radiance RMWs of this launch
+    uint32_t cap;                    // region size in rays (a multiple of R*256)
     Stats *stats;
     uint32_t bounce;
     uint32_t pass;
@@ -353,53 +382,85 @@ template <class T> struct BounceArgs {
 // Per-bounce wavefront kernel.  FIRST generates the camera ray in registers (no queue read)
 // and stores the path's first radiance term; later bounces read compacted rays, RMW the path
 // radiance only when the segment contributes, and append survivors to the other queue.
-// Compaction: wave64 ballot + popcount prefix, per-block aggregation in LDS, ONE global
-// atomicAdd per block per R*256 rays; survivors of a wave land in consecutive queue slots,
-// so the 16-byte packet stores coalesce.
+//
+// Queue ownership: the grid size G is the same for every bounce of a pass and workgroup b owns the
+// fixed region [b*cap, (b+1)*cap) of BOTH queues (cap >= the rays b starts with, survivors only
+// shrink).  It appends its survivors there and leaves their number in cnt_out[b]; the next bounce's
+// workgroup b reads exactly that region.  No global atomic, no inter-workgroup traffic, and the same
+// XCD (b mod 8 under round-robin dispatch) touches a region in consecutive bounces.  FIRST deals the
+// pass's chunks round-robin (chunk c -> workgroup c mod G), which spreads every image region over all
+// workgroups, so the regions stay balanced as rays die.
+//
+// A workgroup handles chunks of R*256 rays in three phases (two barriers per chunk):
+//   1. every lane: R x (load | generate ray, closest hit, radiance terms, throughput); rays that scatter
+//      and need random_in_unit_sphere() append their RNG key to a work list in LDS;
+//   2. the workgroup drains that list cooperatively: a lane keeps trying one entry until it is accepted,
+//      then pulls the next entry (wave-aggregated LDS atomic) — lanes do not idle behind the slowest
+//      rejection loop of their wave;
+//   3. every lane: finish the directions; compaction by wave64 ballot + popcount prefix, one LDS atomic
+//      per wave for its slice of the workgroup's region; a wave's survivors land in consecutive slots,
+//      so the 16-byte packet stores coalesce.
+// Results do not depend on which lane produced a random vector: it is a pure function of its key.
 template <class T, bool FIRST, int R>
 __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
-    // compaction scratch lives behind the scene in the one dynamic LDS block (no static __shared__
-    // in front of it, so the base stays 32-byte aligned)
-    uint32_t(*s_wave_cnt)[4] = reinterpret_cast<uint32_t(*)[4]>(
-        lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles));   // [kBlock/64][4 >= R]
-    uint32_t &s_base = s_wave_cnt[kBlock / 64][0];
-    const RenderConst<T> &rc = a.rc;
+    // scratch behind the scene in the one dynamic LDS block (no static __shared__ in front of it, so the
+    // base stays 32-byte aligned): control words, then two rnd work lists (double-buffered by chunk parity)
+    unsigned char *scratch = lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles);
+    uint32_t *s_ctrl = reinterpret_cast<uint32_t *>(scratch);       // [2p] list length, [2p+1] next entry (p = parity); [4] region fill
     constexpr uint32_t CH = kBlock * R;
-    const uint32_t n_in = FIRST ? a.n_first : a.counts[a.bounce];
-    if (blockIdx.x * CH >= n_in) return;       // block-uniform: surplus blocks of a late bounce leave before staging
-    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    Pack4<T> *s_rnd0 = reinterpret_cast<Pack4<T> *>(scratch + kCompactScratchBytes);   // [2][CH] key in, vector out
+    const RenderConst<T> &rc = a.rc;
+    const uint32_t G = gridDim.x, bid = blockIdx.x;
     const bool scatter = (a.bounce + 1 < rc.max_depth);
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long n_rmw = 0;
+    // rays of this workgroup: FIRST -> chunks bid, bid+G, ... of [0, n_first); else its own queue region
+    const uint32_t n_mine = FIRST ? 0u : a.cnt_in[bid];
+    const uint32_t region = bid * a.cap;
+    if (!FIRST && n_mine == 0) {                    // block-uniform: nothing left in this region
+        if (threadIdx.x == 0) { if (scatter) a.cnt_out[bid] = 0; a.blk_stats[2 * bid] = 0; a.blk_stats[2 * bid + 1] = 0; }
+        return;
+    }
+    if (threadIdx.x == 0) { s_ctrl[0] = 0; s_ctrl[1] = kBlock; s_ctrl[2] = 0; s_ctrl[3] = kBlock; s_ctrl[4] = 0; s_ctrl[5] = 0; s_ctrl[6] = 0; }
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // ends with __syncthreads()
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t n_rmw = 0, n_seg = 0;
+    uint32_t parity = 0;
 
-    for (uint32_t base = blockIdx.x * CH; base < n_in; base += gridDim.x * CH) {
-        Vec<T> o[R], d[R], beta[R];
-        uint32_t q[R];
-        bool alive[R];
-        uint32_t pre[R];
+    const uint32_t n_chunks = FIRST ? (a.n_first + CH - 1) / CH : (n_mine + CH - 1) / CH;
+    for (uint32_t chunk = FIRST ? bid : 0u; chunk < n_chunks; chunk += FIRST ? G : 1u, parity ^= 1u) {
+        Vec<T> o[R], beta[R];
+        Pending<T> pend[R];
+        uint32_t q[R], ent[R];
+        uint32_t *ctl = s_ctrl + 2 * parity;
+        Pack4<T> *s_rnd = s_rnd0 + parity * CH;
+        const uint32_t limit = FIRST ? a.n_first : n_mine;
+        // ---------------- phase 1
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t idx = base + r * kBlock + threadIdx.x;
-            alive[r] = false;
-            if (idx < n_in) {
+            const uint32_t idx = chunk * CH + r * kBlock + threadIdx.x;
+            pend[r].kind = kDead;
+            bool want = false;
+            RngKey key;
+            if (idx < limit) {
                 uint32_t pixel, sample, pi, pj;
+                Vec<T> d;
                 if (FIRST) {
                     q[r] = idx;
                     path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
-                    camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d[r]);
+                    camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
                     beta[r] = mk<T>(1, 1, 1);
                 } else {
-                    const Pack4<T> A = a.qin.A[idx], B = a.qin.B[idx];
-                    const Pack2<T> C = a.qin.C[idx];
+                    const Pack4<T> A = a.qin.A[region + idx], B = a.qin.B[region + idx];
+                    const Pack2<T> C = a.qin.C[region + idx];
                     o[r] = mk<T>(A.x, A.y, A.z);
-                    d[r] = mk<T>(A.w, B.x, B.y);
+                    d = mk<T>(A.w, B.x, B.y);
                     beta[r] = mk<T>(B.z, B.w, C.x);
                     q[r] = Bits<T>::to_u32(C.y);
-                    path_of<T>(rc, q[r], a.pass, pi, pj, pixel, sample);
                 }
                 Vec<T> contrib; T t_hit;
-                SegInfo si = trace_segment<T>(sc, rc, o[r], d[r], beta[r], pixel, sample, a.bounce, scatter, contrib, t_hit);
+                SegInfo si = segment_front<T>(sc, o[r], d, beta[r], scatter, contrib, t_hit, pend[r]);
+                ++n_seg;
                 if (FIRST) {
                     Pack4<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z; l.w = 0;
                     if (!si.has_contrib) { l.x = 0; l.y = 0; l.z = 0; }
@@ -410,50 +471,103 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
                     a.L[q[r]] = l;
                     ++n_rmw;
                 }
-                alive[r] = si.alive;
-            }
-            const unsigned long long m = __ballot(alive[r]);
-            pre[r] = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wave_cnt[wave][r] = __popcll(m);
-        }
-        if (scatter) {           // uniform: the last bounce never enqueues
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t tot = 0;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    for (int w = 0; w < kBlock / 64; ++w) tot += s_wave_cnt[w][r];
-                s_base = tot ? atomicAdd(&a.counts[a.bounce + 1], tot) : 0u;
-            }
-            __syncthreads();
-            uint32_t off = s_base;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-#pragma unroll
-                for (int w = 0; w < kBlock / 64; ++w) {
-                    const uint32_t c = s_wave_cnt[w][r];
-                    if (w == (int)wave && alive[r]) {
-                        const uint32_t dst = off + pre[r];
-                        Pack4<T> A, B; Pack2<T> C;
-                        A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = d[r].x;
-                        B.x = d[r].y; B.y = d[r].z; B.z = beta[r].x; B.w = beta[r].y;
-                        C.x = beta[r].z; C.y = Bits<T>::from_u32(q[r]);
-                        a.qout.A[dst] = A; a.qout.B[dst] = B; a.qout.C[dst] = C;
-                    }
-                    off += c;
+                want = (pend[r].kind == kDiffuse || pend[r].kind == kSpecRough);
+                if (want) {
+                    if (!FIRST) path_of<T>(rc, q[r], a.pass, pi, pj, pixel, sample);
+                    key = rng_key(rc.sA, rc.sB, pixel, sample, a.bounce);
                 }
             }
-            __syncthreads();     // s_wave_cnt / s_base are rewritten by the next chunk
+            if (scatter) {
+                const unsigned long long m = __ballot(want);
+                if (want) {                                   // wave-aggregated append to the LDS work list
+                    const uint32_t rank = __popcll(m & lt_mask);
+                    uint32_t b0 = 0;
+                    if (rank == 0) b0 = atomicAdd(&ctl[0], (uint32_t)__popcll(m));
+                    b0 = __builtin_amdgcn_readfirstlane(b0);  // first active lane of this branch is the rank-0 lane
+                    ent[r] = b0 + rank;
+                    uint32_t *kw = reinterpret_cast<uint32_t *>(&s_rnd[ent[r]]);
+                    kw[0] = key.hA; kw[1] = key.hB;
+                }
+            }
+        }
+        if (!scatter) continue;        // uniform: the last bounce neither scatters nor enqueues
+        __syncthreads();
+        // the other parity's list is idle now (its readers passed the barrier above): reset it for the next chunk
+        if (threadIdx.x == 0) { s_ctrl[2 * (parity ^ 1u)] = 0; s_ctrl[2 * (parity ^ 1u) + 1] = kBlock; }
+        // ---------------- phase 2: cooperative random_in_unit_sphere() over the work list
+        {
+            const uint32_t n_list = ctl[0];
+            uint32_t e = threadIdx.x, t = 1;
+            bool have = e < n_list;
+            RngKey k; k.hA = 0; k.hB = 0; k.hBr = 0;
+            if (have) {
+                const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
+                k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
+            }
+            while (__any(have)) {
+                bool done = false;
+                if (have) {
+                    T u0, u1, u2;
+                    rng3<T>(k, t, u0, u1, u2, (T)(1.0 / 1048576.0));
+                    Vec<T> c = mk<T>(u0, u1, u2) - mk<T>(1, 1, 1);                   // :311
+                    done = dot(c, c) < (T)1.0;                                      // :312
+                    if (!done && t == kMaxTries) { c = mk<T>(0, 0, 0); done = true; }
+                    if (done) { Pack4<T> w; w.x = c.x; w.y = c.y; w.z = c.z; w.w = 0; s_rnd[e] = w; }
+                    ++t;
+                }
+                const unsigned long long m = __ballot(done);
+                if (done) {                                   // pull the next entry
+                    const uint32_t rank = __popcll(m & lt_mask);
+                    uint32_t b0 = 0;
+                    if (rank == 0) b0 = atomicAdd(&ctl[1], (uint32_t)__popcll(m));
+                    b0 = __builtin_amdgcn_readfirstlane(b0);
+                    e = b0 + rank; t = 1;
+                    have = e < n_list;
+                    if (have) {
+                        const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
+                        k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- phase 3: directions, compaction into this workgroup's region of the out queue
+        uint32_t pre[R], wave_total = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool alive = pend[r].kind != kDead;
+            if (alive) {
+                Vec<T> rnd = mk<T>(0, 0, 0);
+                if (pend[r].kind != kMirror) { const Pack4<T> w = s_rnd[ent[r]]; rnd = mk<T>(w.x, w.y, w.z); }
+                pend[r].v = segment_back<T>(o[r], pend[r], rnd);      // v now holds the new direction
+            }
+            const unsigned long long m = __ballot(alive);
+            pre[r] = wave_total + __popcll(m & lt_mask);
+            wave_total += __popcll(m);
+        }
+        uint32_t off = 0;
+        if (lane == 0 && wave_total) off = atomicAdd(&s_ctrl[4], wave_total);    // LDS: this wave's slice of the region
+        off = __builtin_amdgcn_readfirstlane(off) + region;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (pend[r].kind != kDead) {
+                const uint32_t dst = off + pre[r];
+                Pack4<T> A, B; Pack2<T> C;
+                A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = pend[r].v.x;
+                B.x = pend[r].v.y; B.y = pend[r].v.z; B.z = beta[r].x; B.w = beta[r].y;
+                C.x = beta[r].z; C.y = Bits<T>::from_u32(q[r]);
+                a.qout.A[dst] = A; a.qout.B[dst] = B; a.qout.C[dst] = C;
+            }
         }
     }
-    // statistics: one atomic per block
-    if (!FIRST) {
-        for (int sft = 32; sft > 0; sft >>= 1) n_rmw += __shfl_down(n_rmw, sft);
-        if (lane == 0 && n_rmw) atomicAdd(&a.stats->radiance_rmw, n_rmw);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&a.stats->segments, (unsigned long long)n_in);
-        if (!FIRST) atomicAdd(&a.stats->rays_enqueued, (unsigned long long)n_in);
+    // per-workgroup results: survivors in the region, statistics (summed by k_resolve; no global atomics)
+    for (int sft = 32; sft > 0; sft >>= 1) { n_rmw += __shfl_down(n_rmw, sft); n_seg += __shfl_down(n_seg, sft); }
+    if (lane == 0) { atomicAdd(&s_ctrl[5], n_seg); atomicAdd(&s_ctrl[6], n_rmw); }
+    __syncthreads();                  // every wave has allocated its last region slice and added its counts
+    if (threadIdx.x == 0) {
+        if (scatter) a.cnt_out[bid] = s_ctrl[4];
+        a.blk_stats[2 * bid] = s_ctrl[5];
+        a.blk_stats[2 * bid + 1] = s_ctrl[6];
     }
 }
 
@@ -514,8 +628,10 @@ __global__ __launch_bounds__(64) void k_trace(const BounceArgs<T> a, const uint3
 
 // Per-pass resolve: accum[pix] += L[slot][pix] for slot = 0..k_eff-1, in sample order — the
 // `color = color + ray_color(...)` of examples/julia-raytracer.jl:401 in the same order.
+// Workgroup 0 also folds the pass's per-workgroup statistics [n_bounce][G][2] into the render totals.
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack4<T> *L, uint32_t tile_pixels, uint32_t k_eff, int first_pass) {
+__global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack4<T> *L, uint32_t tile_pixels, uint32_t k_eff, int first_pass,
+                                                    const uint32_t *blk_stats, uint32_t n_bounce, uint32_t G, Stats *stats) {
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < tile_pixels; p += gridDim.x * kBlock) {
         Pack4<T> acc;
         if (first_pass) { acc.x = 0; acc.y = 0; acc.z = 0; acc.w = 0; } else acc = accum[p];
@@ -524,6 +640,22 @@ __global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack4
             acc.x = acc.x + l.x; acc.y = acc.y + l.y; acc.z = acc.z + l.z;
         }
         accum[p] = acc;
+    }
+    if (blockIdx.x == 0 && blk_stats) {
+        __shared__ unsigned long long red[3];
+        if (threadIdx.x < 3) red[threadIdx.x] = 0;
+        __syncthreads();
+        unsigned long long seg = 0, enq = 0, rmw = 0;
+        for (uint32_t i = threadIdx.x; i < n_bounce * G; i += kBlock) {
+            const unsigned long long n = blk_stats[2 * i];
+            seg += n;
+            if (i >= G) enq += n;                 // rays read from a queue == rays written to one
+            rmw += blk_stats[2 * i + 1];
+        }
+        for (int sft = 32; sft > 0; sft >>= 1) { seg += __shfl_down(seg, sft); enq += __shfl_down(enq, sft); rmw += __shfl_down(rmw, sft); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], seg); atomicAdd(&red[1], enq); atomicAdd(&red[2], rmw); }
+        __syncthreads();
+        if (threadIdx.x == 0) { stats->segments += red[0]; stats->rays_enqueued += red[1]; stats->radiance_rmw += red[2]; }
     }
 }
 

@@ -54,7 +54,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], L, accum, counts, stats, scene, out_tmp, trace;
+    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, scene, out_tmp, trace;
     spira::Stats *h_stats = nullptr;          // pinned
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> ev_pool;          // profile mode: pairs around bounce launches
@@ -244,18 +244,28 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     int R = (int)env_u32("SPIRA_R", 4);
     if (R != 1 && R != 2 && R != 4) R = 4;
 
+    // ---- launch geometry: G workgroups per bounce kernel, each owning `cap` rays of both queues
+    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", 8);
+    const uint32_t ch = spira::kBlock * R;
+    const uint32_t n_chunks_max = (uint32_t)((batch + ch - 1) / ch);
+    const uint32_t G_max = std::min<uint32_t>(n_chunks_max, max_blocks);
+    const uint64_t cap_max = (uint64_t)((n_chunks_max + G_max - 1) / G_max) * ch;
+    const uint64_t q_rays = cap_max * G_max;
+    if (q_rays > 0xFFFFFFFFull) return fail(SPIRA_E_LIMIT, "pass too large");
+
     // ---- workspaces (cached per device, grown on demand; sized for 288 GB HBM: no chunking of a pass)
     using P4 = spira::Pack4<T>;
     using P2 = spira::Pack2<T>;
     if (!mega && p->max_depth > 1)
         for (int i = 0; i < 2; ++i) {
-            if (int rc = c.qA[i].ensure(batch * sizeof(P4))) return rc;
-            if (int rc = c.qB[i].ensure(batch * sizeof(P4))) return rc;
-            if (int rc = c.qC[i].ensure(batch * sizeof(P2))) return rc;
+            if (int rc = c.qA[i].ensure(q_rays * sizeof(P4))) return rc;
+            if (int rc = c.qB[i].ensure(q_rays * sizeof(P4))) return rc;
+            if (int rc = c.qC[i].ensure(q_rays * sizeof(P2))) return rc;
         }
     if (int rc = c.L.ensure(batch * sizeof(P4))) return rc;
     if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
-    if (int rc = c.counts.ensure((SPIRA_MAX_DEPTH + 2) * sizeof(uint32_t))) return rc;
+    if (int rc = c.counts.ensure((size_t)(SPIRA_MAX_DEPTH + 2) * G_max * sizeof(uint32_t))) return rc;
+    if (int rc = c.blkstats.ensure((size_t)(SPIRA_MAX_DEPTH + 1) * G_max * 2 * sizeof(uint32_t))) return rc;
     if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
 
     spira::BounceArgs<T> a{};
@@ -265,12 +275,10 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
         !fastdiv_selfcheck(a.rc.stripe_h ? a.rc.stripe_h : 1, rows))
         return fail(SPIRA_E_LIMIT, "internal: fast division self-check failed");
     a.L = (P4 *)c.L.p;
-    a.counts = (uint32_t *)c.counts.p;
     a.stats = (spira::Stats *)c.stats.p;
 
     const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + spira::kCompactScratchBytes;
     const uint32_t n_pass = (p->spp + slots - 1) / slots;
-    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", 8);
 
     T *d_hdr = out_hdr, *d_img = out_img;
     if (!out_on_device) {
@@ -299,29 +307,35 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
             const uint32_t n_first = (uint32_t)((uint64_t)k_eff * tile_pixels);
             a.pass = pass;
             a.n_first = n_first;
+            uint32_t G = 0;
             if (mega) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
                 hipLaunchKernelGGL((spira::k_mega<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 ++launches;
             } else {
-                HIP_TRY(hipMemsetAsync(c.counts.p, 0, (p->max_depth + 2) * sizeof(uint32_t), st));
-                const uint32_t ch = spira::kBlock * R;
-                uint32_t blocks = std::min<uint32_t>((n_first + ch - 1) / ch, max_blocks);
+                const uint32_t n_chunks = (n_first + ch - 1) / ch;
+                G = std::min<uint32_t>(n_chunks, max_blocks);
+                a.cap = ((n_chunks + G - 1) / G) * ch;
                 for (uint32_t b = 0; b < p->max_depth; ++b) {
                     a.bounce = b;
                     int qi = b & 1;      // bounce b writes queue qi, reads queue qi^1
                     a.qout = {(P4 *)c.qA[qi].p, (P4 *)c.qB[qi].p, (P2 *)c.qC[qi].p};
                     a.qin = {(P4 *)c.qA[qi ^ 1].p, (P4 *)c.qB[qi ^ 1].p, (P2 *)c.qC[qi ^ 1].p};
+                    a.cnt_in = (const uint32_t *)c.counts.p + (size_t)b * G;
+                    a.cnt_out = (uint32_t *)c.counts.p + (size_t)(b + 1) * G;
+                    a.blk_stats = (uint32_t *)c.blkstats.p + (size_t)b * G * 2;
                     if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
-                    if (b == 0) launch_bounce<T, true>(R, dim3(blocks), lds, st, a);
-                    else launch_bounce<T, false>(R, dim3(blocks), lds, st, a);
+                    const size_t lds_b = lds + 2 * (size_t)ch * sizeof(P4);  // + two rnd work lists (one slot per ray of a chunk)
+                    if (b == 0) launch_bounce<T, true>(R, dim3(G), lds_b, st, a);
+                    else launch_bounce<T, false>(R, dim3(G), lds_b, st, a);
                     if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                     ++launches;
                 }
             }
             uint32_t rblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
             hipLaunchKernelGGL((spira::k_resolve<T>), dim3(rblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const P4 *)c.L.p,
-                               (uint32_t)tile_pixels, k_eff, pass == 0 ? 1 : 0);
+                               (uint32_t)tile_pixels, k_eff, pass == 0 ? 1 : 0, mega ? (const uint32_t *)nullptr : (const uint32_t *)c.blkstats.p,
+                               p->max_depth, G, (spira::Stats *)c.stats.p);
             ++launches;
         }
     }
@@ -483,7 +497,7 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); }
-        c.L.release(); c.accum.release(); c.counts.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release();
+        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
         (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop);
