@@ -13,7 +13,7 @@ namespace spira {
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr uint32_t kMaxTries = 64;   // bounded rejection sampling (P(exhaust) ~ 2e-21)
-constexpr size_t kCompactScratchBytes = 96;   // [kBlock/64][4] wave counts + control words, behind the LDS scene
+constexpr size_t kCompactScratchBytes = 0;    // (k_bounce keeps one work list per wave behind the LDS scene)
 
 // ------------------------------------------------------------------ small vector algebra
 // Operation order mirrors Vec3 of examples/julia-raytracer.jl:11-41.
@@ -369,76 +369,85 @@ template <class T> struct BounceArgs {
     RenderConst<T> rc;
     RayQueue<T> qin, qout;
     Pack4<T> *L;                     // per-path radiance of the pass batch (slot-major), 16/32 B each
-    const uint32_t *cnt_in;          // [G] rays waiting in each workgroup's region of qin (bounce >= 1)
-    uint32_t *cnt_out;               // [G] survivors this bounce leaves in each region of qout
-    uint32_t *blk_stats;             // [G][2] segments traced, radiance RMWs of this launch
-    uint32_t cap;                    // region size in rays (a multiple of R*256)
+    const uint32_t *cnt_in;          // [NW] rays waiting in each wave's region of qin (bounce >= 1)
+    uint32_t *cnt_out;               // [NW] survivors this bounce leaves in each region of qout
+    uint32_t *blk_stats;             // [NW][2] segments traced, radiance RMWs of this launch
+    uint32_t cap;                    // region size in rays (a multiple of R*64)
     Stats *stats;
     uint32_t bounce;
     uint32_t pass;
     uint32_t n_first;                // FIRST: number of paths in this pass
 };
 
+// Order this wave's LDS traffic: DS operations of one wave execute in issue order, so a wave-scope
+// fence (no instructions, only a compiler barrier) is all that lanes of ONE wave need to exchange data.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Per-bounce wavefront kernel.  FIRST generates the camera ray in registers (no queue read)
 // and stores the path's first radiance term; later bounces read compacted rays, RMW the path
 // radiance only when the segment contributes, and append survivors to the other queue.
 //
-// Queue ownership: the grid size G is the same for every bounce of a pass and workgroup b owns the
-// fixed region [b*cap, (b+1)*cap) of BOTH queues (cap >= the rays b starts with, survivors only
-// shrink).  It appends its survivors there and leaves their number in cnt_out[b]; the next bounce's
-// workgroup b reads exactly that region.  No global atomic, no inter-workgroup traffic, and the same
-// XCD (b mod 8 under round-robin dispatch) touches a region in consecutive bounces.  FIRST deals the
-// pass's chunks round-robin (chunk c -> workgroup c mod G), which spreads every image region over all
-// workgroups, so the regions stay balanced as rays die.
+// Every WAVE is an autonomous worker: the launch has NW = 4*gridDim.x waves, the same for every
+// bounce of a pass, and wave w owns the fixed region [w*cap, (w+1)*cap) of BOTH queues (cap >= the rays
+// w starts with; survivors only shrink).  It appends its survivors there and leaves their number in
+// cnt_out[w]; the next bounce's wave w reads exactly that region.  Hence: no global atomic, no LDS
+// atomic, no workgroup barrier after the scene is staged, no inter-wave traffic; the same CU slot / XCD
+// (w mod 8 workgroups under round-robin dispatch) touches a region in consecutive bounces.  FIRST deals
+// the pass's 64*R-ray sub-chunks round-robin over the waves, which spreads every image region over all
+// waves, so the regions stay balanced as rays die.
 //
-// A workgroup handles chunks of R*256 rays in three phases (two barriers per chunk):
+// A wave handles sub-chunks of R*64 rays in three phases:
 //   1. every lane: R x (load | generate ray, closest hit, radiance terms, throughput); rays that scatter
-//      and need random_in_unit_sphere() append their RNG key to a work list in LDS;
-//   2. the workgroup drains that list cooperatively: a lane keeps trying one entry until it is accepted,
-//      then pulls the next entry (wave-aggregated LDS atomic) — lanes do not idle behind the slowest
-//      rejection loop of their wave;
-//   3. every lane: finish the directions; compaction by wave64 ballot + popcount prefix, one LDS atomic
-//      per wave for its slice of the workgroup's region; a wave's survivors land in consecutive slots,
-//      so the 16-byte packet stores coalesce.
+//      and need random_in_unit_sphere() append their RNG key to the wave's work list in LDS (slot index
+//      from a ballot prefix; the list length is a wave-uniform register);
+//   2. the wave drains the list cooperatively: a lane keeps trying one entry until it is accepted, then
+//      takes the next unclaimed entry (ballot prefix again) — lanes do not idle behind the slowest
+//      rejection loop of the wave (mean 1.9 tries, wave maximum ~6);
+//   3. every lane: finish the directions; compaction by wave64 ballot + popcount prefix straight into
+//      the wave's region; survivors land in consecutive slots, so the 16-byte packet stores coalesce.
 // Results do not depend on which lane produced a random vector: it is a pure function of its key.
 template <class T, bool FIRST, int R>
 __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
-    // scratch behind the scene in the one dynamic LDS block (no static __shared__ in front of it, so the
-    // base stays 32-byte aligned): control words, then two rnd work lists (double-buffered by chunk parity)
-    unsigned char *scratch = lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles);
-    uint32_t *s_ctrl = reinterpret_cast<uint32_t *>(scratch);       // [2p] list length, [2p+1] next entry (p = parity); [4] region fill
-    constexpr uint32_t CH = kBlock * R;
-    Pack4<T> *s_rnd0 = reinterpret_cast<Pack4<T> *>(scratch + kCompactScratchBytes);   // [2][CH] key in, vector out
+    constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t NW = gridDim.x * WPB, wid = blockIdx.x * WPB + wave;
     const RenderConst<T> &rc = a.rc;
-    const uint32_t G = gridDim.x, bid = blockIdx.x;
     const bool scatter = (a.bounce + 1 < rc.max_depth);
-    // rays of this workgroup: FIRST -> chunks bid, bid+G, ... of [0, n_first); else its own queue region
-    const uint32_t n_mine = FIRST ? 0u : a.cnt_in[bid];
-    const uint32_t region = bid * a.cap;
-    if (!FIRST && n_mine == 0) {                    // block-uniform: nothing left in this region
-        if (threadIdx.x == 0) { if (scatter) a.cnt_out[bid] = 0; a.blk_stats[2 * bid] = 0; a.blk_stats[2 * bid + 1] = 0; }
-        return;
+    // this wave's rays: FIRST -> sub-chunks wid, wid+NW, ... of [0, n_first); else its own queue region
+    uint32_t n_mine = 0;
+    if (!FIRST) {
+        uint32_t n_blk = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < WPB; ++w) n_blk += a.cnt_in[blockIdx.x * WPB + w];
+        n_mine = a.cnt_in[wid];
+        if (n_blk == 0) {                           // block-uniform: nothing left in this workgroup's regions
+            if (lane == 0) { if (scatter) a.cnt_out[wid] = 0; a.blk_stats[2 * wid] = 0; a.blk_stats[2 * wid + 1] = 0; }
+            return;
+        }
     }
-    if (threadIdx.x == 0) { s_ctrl[0] = 0; s_ctrl[1] = kBlock; s_ctrl[2] = 0; s_ctrl[3] = kBlock; s_ctrl[4] = 0; s_ctrl[5] = 0; s_ctrl[6] = 0; }
-    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // ends with __syncthreads()
-    const uint32_t lane = threadIdx.x & 63;
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // the only workgroup barrier of the kernel
+    // the wave's private work list sits behind the scene in the one dynamic LDS block
+    Pack4<T> *s_rnd = reinterpret_cast<Pack4<T> *>(lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles)) + wave * SUB;
+    const uint32_t region = wid * a.cap;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t n_rmw = 0, n_seg = 0;
-    uint32_t parity = 0;
+    uint32_t n_rmw = 0, n_seg = 0, fill = 0;
 
-    const uint32_t n_chunks = FIRST ? (a.n_first + CH - 1) / CH : (n_mine + CH - 1) / CH;
-    for (uint32_t chunk = FIRST ? bid : 0u; chunk < n_chunks; chunk += FIRST ? G : 1u, parity ^= 1u) {
+    const uint32_t limit = FIRST ? a.n_first : n_mine;
+    const uint32_t n_sub = (limit + SUB - 1) / SUB;
+    for (uint32_t sub = FIRST ? wid : 0u; sub < n_sub; sub += FIRST ? NW : 1u) {
         Vec<T> o[R], beta[R];
         Pending<T> pend[R];
         uint32_t q[R], ent[R];
-        uint32_t *ctl = s_ctrl + 2 * parity;
-        Pack4<T> *s_rnd = s_rnd0 + parity * CH;
-        const uint32_t limit = FIRST ? a.n_first : n_mine;
+        uint32_t n_list = 0;
         // ---------------- phase 1
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t idx = chunk * CH + r * kBlock + threadIdx.x;
+            const uint32_t idx = sub * SUB + r * 64 + lane;
             pend[r].kind = kDead;
             bool want = false;
             RngKey key;
@@ -479,25 +488,19 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
             }
             if (scatter) {
                 const unsigned long long m = __ballot(want);
-                if (want) {                                   // wave-aggregated append to the LDS work list
-                    const uint32_t rank = __popcll(m & lt_mask);
-                    uint32_t b0 = 0;
-                    if (rank == 0) b0 = atomicAdd(&ctl[0], (uint32_t)__popcll(m));
-                    b0 = __builtin_amdgcn_readfirstlane(b0);  // first active lane of this branch is the rank-0 lane
-                    ent[r] = b0 + rank;
+                if (want) {                                   // append to the wave's work list
+                    ent[r] = n_list + __popcll(m & lt_mask);
                     uint32_t *kw = reinterpret_cast<uint32_t *>(&s_rnd[ent[r]]);
                     kw[0] = key.hA; kw[1] = key.hB;
                 }
+                n_list += (uint32_t)__popcll(m);
             }
         }
         if (!scatter) continue;        // uniform: the last bounce neither scatters nor enqueues
-        __syncthreads();
-        // the other parity's list is idle now (its readers passed the barrier above): reset it for the next chunk
-        if (threadIdx.x == 0) { s_ctrl[2 * (parity ^ 1u)] = 0; s_ctrl[2 * (parity ^ 1u) + 1] = kBlock; }
-        // ---------------- phase 2: cooperative random_in_unit_sphere() over the work list
+        wave_lds_sync();
+        // ---------------- phase 2: cooperative random_in_unit_sphere() over the wave's work list
         {
-            const uint32_t n_list = ctl[0];
-            uint32_t e = threadIdx.x, t = 1;
+            uint32_t e = lane, t = 1, next = 64;
             bool have = e < n_list;
             RngKey k; k.hA = 0; k.hB = 0; k.hBr = 0;
             if (have) {
@@ -516,58 +519,44 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
                     ++t;
                 }
                 const unsigned long long m = __ballot(done);
-                if (done) {                                   // pull the next entry
-                    const uint32_t rank = __popcll(m & lt_mask);
-                    uint32_t b0 = 0;
-                    if (rank == 0) b0 = atomicAdd(&ctl[1], (uint32_t)__popcll(m));
-                    b0 = __builtin_amdgcn_readfirstlane(b0);
-                    e = b0 + rank; t = 1;
+                if (done) {                                   // take the next unclaimed entry
+                    e = next + __popcll(m & lt_mask); t = 1;
                     have = e < n_list;
                     if (have) {
                         const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
                         k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
                     }
                 }
+                next += (uint32_t)__popcll(m);
             }
         }
-        __syncthreads();
-        // ---------------- phase 3: directions, compaction into this workgroup's region of the out queue
-        uint32_t pre[R], wave_total = 0;
+        wave_lds_sync();
+        // ---------------- phase 3: directions, compaction into this wave's region of the out queue
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool alive = pend[r].kind != kDead;
+            const unsigned long long m = __ballot(alive);
             if (alive) {
                 Vec<T> rnd = mk<T>(0, 0, 0);
                 if (pend[r].kind != kMirror) { const Pack4<T> w = s_rnd[ent[r]]; rnd = mk<T>(w.x, w.y, w.z); }
-                pend[r].v = segment_back<T>(o[r], pend[r], rnd);      // v now holds the new direction
-            }
-            const unsigned long long m = __ballot(alive);
-            pre[r] = wave_total + __popcll(m & lt_mask);
-            wave_total += __popcll(m);
-        }
-        uint32_t off = 0;
-        if (lane == 0 && wave_total) off = atomicAdd(&s_ctrl[4], wave_total);    // LDS: this wave's slice of the region
-        off = __builtin_amdgcn_readfirstlane(off) + region;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (pend[r].kind != kDead) {
-                const uint32_t dst = off + pre[r];
+                const Vec<T> nd = segment_back<T>(o[r], pend[r], rnd);
+                const uint32_t dst = region + fill + __popcll(m & lt_mask);
                 Pack4<T> A, B; Pack2<T> C;
-                A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = pend[r].v.x;
-                B.x = pend[r].v.y; B.y = pend[r].v.z; B.z = beta[r].x; B.w = beta[r].y;
+                A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = nd.x;
+                B.x = nd.y; B.y = nd.z; B.z = beta[r].x; B.w = beta[r].y;
                 C.x = beta[r].z; C.y = Bits<T>::from_u32(q[r]);
                 a.qout.A[dst] = A; a.qout.B[dst] = B; a.qout.C[dst] = C;
             }
+            fill += (uint32_t)__popcll(m);
         }
+        wave_lds_sync();      // the list slots are rewritten by the next sub-chunk's phase 1
     }
-    // per-workgroup results: survivors in the region, statistics (summed by k_resolve; no global atomics)
+    // per-wave results: survivors in the region, statistics (summed by k_resolve; no atomics)
     for (int sft = 32; sft > 0; sft >>= 1) { n_rmw += __shfl_down(n_rmw, sft); n_seg += __shfl_down(n_seg, sft); }
-    if (lane == 0) { atomicAdd(&s_ctrl[5], n_seg); atomicAdd(&s_ctrl[6], n_rmw); }
-    __syncthreads();                  // every wave has allocated its last region slice and added its counts
-    if (threadIdx.x == 0) {
-        if (scatter) a.cnt_out[bid] = s_ctrl[4];
-        a.blk_stats[2 * bid] = s_ctrl[5];
-        a.blk_stats[2 * bid + 1] = s_ctrl[6];
+    if (lane == 0) {
+        if (scatter) a.cnt_out[wid] = fill;
+        a.blk_stats[2 * wid] = n_seg;
+        a.blk_stats[2 * wid + 1] = n_rmw;
     }
 }
 

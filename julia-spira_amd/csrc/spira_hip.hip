@@ -241,16 +241,22 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     const uint64_t batch = slots64 * tile_pixels;
     const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA;
     const bool profile = (p->flags & SPIRA_FLAG_PROFILE) != 0;
-    int R = (int)env_u32("SPIRA_R", 4);
-    if (R != 1 && R != 2 && R != 4) R = 4;
+    int R = (int)env_u32("SPIRA_R", 2);
+    if (R != 1 && R != 2 && R != 4) R = 2;
 
-    // ---- launch geometry: G workgroups per bounce kernel, each owning `cap` rays of both queues
-    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", 8);
-    const uint32_t ch = spira::kBlock * R;
-    const uint32_t n_chunks_max = (uint32_t)((batch + ch - 1) / ch);
-    const uint32_t G_max = std::min<uint32_t>(n_chunks_max, max_blocks);
-    const uint64_t cap_max = (uint64_t)((n_chunks_max + G_max - 1) / G_max) * ch;
-    const uint64_t q_rays = cap_max * G_max;
+    // ---- launch geometry: NW = 4*G autonomous waves per bounce kernel, each owning `cap` rays of both queues
+    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", 16);
+    const uint32_t wpb = spira::kBlock / 64;
+    const uint32_t sub = 64 * R;                                   // rays per wave sub-chunk
+    auto geometry = [&](uint64_t n_first, uint32_t &G, uint32_t &cap) {
+        const uint64_t n_sub = (n_first + sub - 1) / sub;
+        G = (uint32_t)std::min<uint64_t>((n_sub + wpb - 1) / wpb, max_blocks);
+        const uint64_t nw = (uint64_t)G * wpb;
+        cap = (uint32_t)(((n_sub + nw - 1) / nw) * sub);
+    };
+    uint32_t G_max = 0, cap_max = 0;
+    geometry(batch, G_max, cap_max);
+    const uint64_t q_rays = (uint64_t)cap_max * G_max * wpb;
     if (q_rays > 0xFFFFFFFFull) return fail(SPIRA_E_LIMIT, "pass too large");
 
     // ---- workspaces (cached per device, grown on demand; sized for 288 GB HBM: no chunking of a pass)
@@ -264,8 +270,8 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
         }
     if (int rc = c.L.ensure(batch * sizeof(P4))) return rc;
     if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
-    if (int rc = c.counts.ensure((size_t)(SPIRA_MAX_DEPTH + 2) * G_max * sizeof(uint32_t))) return rc;
-    if (int rc = c.blkstats.ensure((size_t)(SPIRA_MAX_DEPTH + 1) * G_max * 2 * sizeof(uint32_t))) return rc;
+    if (int rc = c.counts.ensure((size_t)(SPIRA_MAX_DEPTH + 2) * G_max * wpb * sizeof(uint32_t))) return rc;
+    if (int rc = c.blkstats.ensure((size_t)(SPIRA_MAX_DEPTH + 1) * G_max * wpb * 2 * sizeof(uint32_t))) return rc;
     if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
 
     spira::BounceArgs<T> a{};
@@ -313,19 +319,18 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
                 hipLaunchKernelGGL((spira::k_mega<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 ++launches;
             } else {
-                const uint32_t n_chunks = (n_first + ch - 1) / ch;
-                G = std::min<uint32_t>(n_chunks, max_blocks);
-                a.cap = ((n_chunks + G - 1) / G) * ch;
+                geometry(n_first, G, a.cap);
+                const size_t nw = (size_t)G * wpb;
                 for (uint32_t b = 0; b < p->max_depth; ++b) {
                     a.bounce = b;
                     int qi = b & 1;      // bounce b writes queue qi, reads queue qi^1
                     a.qout = {(P4 *)c.qA[qi].p, (P4 *)c.qB[qi].p, (P2 *)c.qC[qi].p};
                     a.qin = {(P4 *)c.qA[qi ^ 1].p, (P4 *)c.qB[qi ^ 1].p, (P2 *)c.qC[qi ^ 1].p};
-                    a.cnt_in = (const uint32_t *)c.counts.p + (size_t)b * G;
-                    a.cnt_out = (uint32_t *)c.counts.p + (size_t)(b + 1) * G;
-                    a.blk_stats = (uint32_t *)c.blkstats.p + (size_t)b * G * 2;
+                    a.cnt_in = (const uint32_t *)c.counts.p + (size_t)b * nw;
+                    a.cnt_out = (uint32_t *)c.counts.p + (size_t)(b + 1) * nw;
+                    a.blk_stats = (uint32_t *)c.blkstats.p + (size_t)b * nw * 2;
                     if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
-                    const size_t lds_b = lds + 2 * (size_t)ch * sizeof(P4);  // + two rnd work lists (one slot per ray of a chunk)
+                    const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4);   // + one work list per wave (one slot per ray of a sub-chunk)
                     if (b == 0) launch_bounce<T, true>(R, dim3(G), lds_b, st, a);
                     else launch_bounce<T, false>(R, dim3(G), lds_b, st, a);
                     if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
@@ -335,7 +340,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
             uint32_t rblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
             hipLaunchKernelGGL((spira::k_resolve<T>), dim3(rblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const P4 *)c.L.p,
                                (uint32_t)tile_pixels, k_eff, pass == 0 ? 1 : 0, mega ? (const uint32_t *)nullptr : (const uint32_t *)c.blkstats.p,
-                               p->max_depth, G, (spira::Stats *)c.stats.p);
+                               p->max_depth, G * wpb, (spira::Stats *)c.stats.p);
             ++launches;
         }
     }
