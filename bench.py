@@ -119,8 +119,13 @@ def main():
             launches = max(1, c["bounce_launches"])
             avg_ms = c["bounce_kernel_ms"] / launches
             achieved = nbytes / (c["bounce_kernel_ms"] * 1e-3) / 1e9 if c["bounce_kernel_ms"] > 0 else 0.0
+            traffic, tsrc = None, None
+            tfile = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.scene, args.prec))
+            if os.path.exists(tfile) and (W, H, spp_total, depth, world) == (1920, 1080, 64, 8, 1):
+                tj = json.load(open(tfile))      # PMC bytes per k_bounce launch of this same command (profiles/run_profile.sh)
+                traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(tfile)
             roof = {"bound": "hbm", "kernel": "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                     "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "bytes_per_sample": round(nbytes / c["samples"], 2), "segments_per_sample": round(c["segments"] / c["samples"], 4),
                     "bounce_kernel_share": round(c["bounce_kernel_ms"] / max(c["kernel_ms"], 1e-9), 4)}
@@ -129,11 +134,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             import oracle_py as O
             cores = O.max_threads()
+            O.render(*sc, O.make_params(W, H, 1, depth, ns, nm, nt, seed=scenes.seed_for(3), rows=8), "f64", n_threads=cores)   # spin up the threads
             t1 = time.perf_counter()
-            O.render(*sc, O.make_params(W, H, 1, depth, ns, nm, nt, seed=scenes.seed_for(3), row0=H // 2, rows=32), "f64", n_threads=cores)
+            O.render(*sc, O.make_params(W, H, 2, depth, ns, nm, nt, seed=scenes.seed_for(3)), "f64", n_threads=cores)
             cal = time.perf_counter() - t1
-            rate = 32 * W / max(cal, 1e-6)                       # samples/s from the calibration slab
-            cpu_spp = max(1, min(args.spp, int(rate * args.cpu_seconds / (W * H))))
+            rate = 2 * W * H / max(cal, 1e-6)                    # samples/s from a whole-frame spp=2 calibration
+            cpu_spp = max(1, min(512, int(rate * args.cpu_seconds / (W * H))))   # short runs read fast: cap the sample
             t1 = time.perf_counter()
             O.render(*sc, O.make_params(W, H, cpu_spp, depth, ns, nm, nt, seed=scenes.seed_for(3)), "f64", n_threads=cores)
             cdt = time.perf_counter() - t1
