@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "mega"])
     ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="all ranks use GPU 0 and the gloo backend (not a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -60,10 +61,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+    if args.rehearse_on_one_gpu:      # N ranks share GPU 0 over gloo: exercises the N>1 code path on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     B.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     W, H, depth = args.width, args.height, args.depth
     spp_total = args.spp * world
