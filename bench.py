@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel PER GPU (total = spp * gpus)")
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3"])
+    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3", "s4"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "mega"])
     ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,7 +73,7 @@ def main():
 
     W, H, depth = args.width, args.height, args.depth
     spp_total = args.spp * world
-    s = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3}[args.scene]()
+    s = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3, "s4": scenes.scene_s4}[args.scene]()
     sc = (s["spheres5"], s["materials8"], s["triangles10"], s["camera12"])
     ns, nm = len(s["spheres5"]), len(s["materials8"])
     nt = 0 if s["triangles10"] is None else len(s["triangles10"])
@@ -161,7 +161,7 @@ def main():
                                    "over %d GPU(s) in 8-row stripes + one RCCL gather" %
                                    (W, H, spp_total, depth, args.scene,
                                     {"s1": "create_scene() of src/spira-metal-optimized.jl", "s2": "create_scene() of examples/julia-raytracer.jl",
-                                     "s3": "S1 inside a closed box"}[args.scene], args.kernel, world),
+                                     "s3": "S1 inside a closed box", "s4": "create_scene_with_obj() of examples/julia-raytracer.jl with an 81 920-triangle procedural mesh (BVH)"}[args.scene], args.kernel, world),
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": args.scene, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},

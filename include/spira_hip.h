@@ -86,8 +86,9 @@ extern "C" {
 /* ---- limits ---- */
 #define SPIRA_MAX_DEPTH        255u        /* bounce index is packed into 8 bits of the RNG key */
 #define SPIRA_MAX_SPP          (1u << 24)  /* sample index is packed into 24 bits of the RNG key */
-#define SPIRA_MAX_LDS_SPHERES  1024u
-#define SPIRA_MAX_LDS_TRIANGLES 1024u      /* linear-scan limit; larger meshes need the BVH path */
+#define SPIRA_MAX_LDS_SPHERES  1024u        /* spheres are always an LDS-resident linear scan */
+#define SPIRA_LDS_TRIANGLES    32u          /* up to this many triangles: LDS linear scan; more: device BVH */
+#define SPIRA_MAX_TRIANGLES    (1u << 24)
 
 /*
  * Render parameters: a superset of RenderParams_jl (src/spira-metal-optimized.jl:390-400).

@@ -87,13 +87,20 @@ template <class T> struct SceneLds {
     const int *smat;
     const int *tmat;
     uint32_t n_spheres, n_triangles;
+    // large meshes: BVH in global memory (spira_bvh.h), L2 / Infinity-Cache resident
+    const Pack4<T> *bvh_nodes;
+    const Pack4<T> *bvh_tris;
+    uint32_t n_bvh_tris;
 };
 
 template <class T> struct SceneGlobal {     // flat arrays exactly as passed through the C ABI
     const T *spheres5;      // prepare_scene_data, src/spira-metal-optimized.jl:515-529
     const T *materials8;    // :531-541
-    const T *triangles10;
+    const T *triangles10;   // staged into LDS (small counts); NULL / 0 when the mesh goes through the BVH
     uint32_t n_spheres, n_materials, n_triangles;
+    const Pack4<T> *bvh_nodes;
+    const Pack4<T> *bvh_tris;
+    uint32_t n_bvh_tris;
 };
 
 template <class T> __host__ __device__ inline size_t scene_lds_bytes(uint32_t ns, uint32_t nm, uint32_t nt) {
@@ -135,6 +142,7 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
     SceneLds<T> sc;
     sc.sph = sph; sc.tri = tri; sc.mat = mat; sc.smat = smat; sc.tmat = tmat;
     sc.n_spheres = g.n_spheres; sc.n_triangles = g.n_triangles;
+    sc.bvh_nodes = g.bvh_nodes; sc.bvh_tris = g.bvh_tris; sc.n_bvh_tris = g.n_bvh_tris;
     return sc;
 }
 
@@ -185,10 +193,95 @@ template <class T> __device__ __forceinline__ uint32_t ref_row_j(const RenderCon
 }
 
 // ------------------------------------------------------------------ closest hit (semantics A)
-// Linear scan with a shrinking t_max, examples/julia-raytracer.jl:242-258; spheres :113-142,
-// triangles :145-187.  Returns the object index (spheres first, then triangles) or -1.
+// Möller–Trumbore, examples/julia-raytracer.jl:145-187, on precomputed edges.  Returns true and t when the
+// triangle is hit with t_min <= t <= t_max (the comparison with the running closest hit is the caller's).
 template <class T>
-__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit) {
+__device__ __forceinline__ bool triangle_test(const Pack4<T> v0, const Pack4<T> e1p, const Pack4<T> e2p, Vec<T> o, Vec<T> d, T t_min, T t_max, T &t_out) {
+    Vec<T> e1 = mk<T>(e1p.x, e1p.y, e1p.z), e2 = mk<T>(e2p.x, e2p.y, e2p.z);
+    Vec<T> h = cross(d, e2);                               // :153
+    T aa = dot(e1, h);                                     // :154
+    if (abs_t(aa) < (T)1e-8) return false;                 // :157
+    T f = (T)1.0 / aa;                                     // :161
+    Vec<T> sv = o - mk<T>(v0.x, v0.y, v0.z);               // :162
+    T u = f * dot(sv, h);                                  // :163
+    if (u < (T)0.0 || u > (T)1.0) return false;            // :165
+    Vec<T> q = cross(sv, e1);                              // :169
+    T v = f * dot(d, q);                                   // :170
+    if (v < (T)0.0 || u + v > (T)1.0) return false;        // :172
+    T t = f * dot(e2, q);                                  // :177
+    if (t < t_min || t > t_max) return false;              // :179
+    t_out = t;
+    return true;
+}
+
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // box tests only (conservative)
+__device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
+__device__ __forceinline__ float min_nn(float a, float b) { return __builtin_fminf(a, b); }  // NaN-ignoring
+__device__ __forceinline__ float max_nn(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double min_nn(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double max_nn(double a, double b) { return __builtin_fmax(a, b); }
+
+constexpr uint32_t kBvhLeafFlagD = 0x80000000u, kBvhNoneD = 0xFFFFFFFFu;
+constexpr int kBvhStackD = 64;
+
+// Conservative ray / padded-box slab test: entry distance, or -1 when the box cannot contain a hit <= best.
+template <class T>
+__device__ __forceinline__ T box_entry(const Pack4<T> mn, const Pack4<T> mx, Vec<T> o, Vec<T> inv, T best) {
+    T x1 = (mn.x - o.x) * inv.x, x2 = (mx.x - o.x) * inv.x;
+    T y1 = (mn.y - o.y) * inv.y, y2 = (mx.y - o.y) * inv.y;
+    T z1 = (mn.z - o.z) * inv.z, z2 = (mx.z - o.z) * inv.z;
+    T enter = max_nn(max_nn(min_nn(x1, x2), min_nn(y1, y2)), min_nn(z1, z2));
+    T exit_ = min_nn(min_nn(max_nn(x1, x2), max_nn(y1, y2)), max_nn(z1, z2));
+    return (enter <= exit_ && exit_ >= (T)0 && enter <= best) ? max_nn(enter, (T)0) : (T)-1;
+}
+
+// BVH traversal that returns exactly what the reference's linear scan over the same triangles returns:
+// minimal t, ties to the LATER triangle of the caller's array (`t > closest_so_far` rejects, :179).
+// `closest` / `prim` come in holding the best hit so far (spheres, LDS triangles) and go out updated;
+// `slot` is the hit triangle's position in the reordered array.
+template <class T>
+__device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, uint32_t &slot) {
+    const Vec<T> inv = mk<T>(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
+    uint32_t stack[kBvhStackD];
+    int sp = 0;
+    uint32_t ref = 0;                                          // root: interior node 0
+    const int base = (int)(sc.n_spheres + sc.n_triangles);
+    while (true) {
+        if (ref & kBvhLeafFlagD) {
+            const uint32_t first = ref & 0x00FFFFFFu, cnt = (ref >> 24) & 0x7Fu;
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                const Pack4<T> v0 = sc.bvh_tris[3 * (size_t)i], e1 = sc.bvh_tris[3 * (size_t)i + 1], e2 = sc.bvh_tris[3 * (size_t)i + 2];
+                T t;
+                if (triangle_test<T>(v0, e1, e2, o, d, t_min, closest, t)) {
+                    const int p = base + (int)Bits<T>::to_u32(v0.w);
+                    if (t < closest || p > prim) { closest = t; prim = p; slot = i; }   // t == closest: the later object wins
+                }
+            }
+        } else {
+            const Pack4<T> l0 = sc.bvh_nodes[4 * (size_t)ref], l1 = sc.bvh_nodes[4 * (size_t)ref + 1];
+            const Pack4<T> r0 = sc.bvh_nodes[4 * (size_t)ref + 2], r1 = sc.bvh_nodes[4 * (size_t)ref + 3];
+            const T tl = box_entry<T>(l0, l1, o, inv, closest), tr = box_entry<T>(r0, r1, o, inv, closest);
+            const uint32_t lref = Bits<T>::to_u32(l0.w), rref = Bits<T>::to_u32(r0.w);
+            const bool hl = tl >= (T)0 && lref != kBvhNoneD, hr = tr >= (T)0 && rref != kBvhNoneD;
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                stack[sp++] = left_first ? rref : lref;
+                ref = left_first ? lref : rref;
+                continue;
+            }
+            if (hl) { ref = lref; continue; }
+            if (hr) { ref = rref; continue; }
+        }
+        if (sp == 0) break;
+        ref = stack[--sp];
+    }
+}
+
+// Linear scan with a shrinking t_max, examples/julia-raytracer.jl:242-258; spheres :113-142, triangles
+// :145-187 (LDS-resident), then the BVH for large meshes.  Returns the object index (spheres first, then
+// triangles in the caller's order) or -1.
+template <class T, bool BVH>
+__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit, uint32_t &slot) {
     T closest = (T)INFINITY;                                   // t_max = Inf, :335
     int prim = -1;
     const T a = dot(d, d);                                     // :115 (same value for every sphere)
@@ -211,22 +304,13 @@ __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<
         }
     }
     for (uint32_t i = 0; i < sc.n_triangles; ++i) {
-        const Pack4<T> v0 = sc.tri[3 * i], e1p = sc.tri[3 * i + 1], e2p = sc.tri[3 * i + 2];
-        Vec<T> e1 = mk<T>(e1p.x, e1p.y, e1p.z), e2 = mk<T>(e2p.x, e2p.y, e2p.z);
-        Vec<T> h = cross(d, e2);                               // :153
-        T aa = dot(e1, h);                                     // :154
-        if (abs_t(aa) < (T)1e-8) continue;                      // :157
-        T f = (T)1.0 / aa;                                     // :161
-        Vec<T> sv = o - mk<T>(v0.x, v0.y, v0.z);               // :162
-        T u = f * dot(sv, h);                                  // :163
-        if (u < (T)0.0 || u > (T)1.0) continue;                // :165
-        Vec<T> q = cross(sv, e1);                              // :169
-        T v = f * dot(d, q);                                   // :170
-        if (v < (T)0.0 || u + v > (T)1.0) continue;            // :172
-        T t = f * dot(e2, q);                                  // :177
-        if (t < t_min || t > closest) continue;                // :179
-        closest = t; prim = (int)(sc.n_spheres + i);
+        T t;
+        if (triangle_test<T>(sc.tri[3 * i], sc.tri[3 * i + 1], sc.tri[3 * i + 2], o, d, t_min, closest, t)) {
+            closest = t; prim = (int)(sc.n_spheres + i);
+        }
     }
+    slot = 0;
+    if (BVH) bvh_closest_hit<T>(sc, o, d, t_min, closest, prim, slot);
     t_hit = closest;
     return prim;
 }
@@ -255,12 +339,13 @@ enum : uint32_t { kDead = 0, kDiffuse = 1, kSpecRough = 2, kMirror = 3 };
 template <class T> struct Pending { Vec<T> v; T rough; uint32_t kind; };   // v = pos + n (diffuse) | reflected (specular)
 struct SegInfo { int prim; bool alive; bool has_contrib; };
 
-template <class T>
+template <class T, bool BVH>
 __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &o, const Vec<T> d, Vec<T> &beta, bool scatter,
                                                  Vec<T> &contrib, T &t_out, Pending<T> &pend) {
     SegInfo info;
     T t;
-    int prim = closest_hit<T>(sc, o, d, (T)0.001, t);                        // :335
+    uint32_t slot;
+    int prim = closest_hit<T, BVH>(sc, o, d, (T)0.001, t, slot);             // :335
     info.prim = prim;
     t_out = prim >= 0 ? t : (T)0;
     pend.kind = kDead; pend.rough = 0; pend.v = mk<T>(0, 0, 0);
@@ -278,11 +363,15 @@ __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &
         const Pack4<T> c = sc.sph[prim];
         n = normalize(pos - mk<T>(c.x, c.y, c.z));                           // :139
         mi = sc.smat[prim];
-    } else {
+    } else if (!BVH || prim < (int)(sc.n_spheres + sc.n_triangles)) {
         int ti = prim - (int)sc.n_spheres;
         const Pack4<T> e1p = sc.tri[3 * ti + 1], e2p = sc.tri[3 * ti + 2];
         n = normalize(cross(mk<T>(e1p.x, e1p.y, e1p.z), mk<T>(e2p.x, e2p.y, e2p.z)));   // :105-109
         mi = sc.tmat[ti];
+    } else {
+        const Pack4<T> e1p = sc.bvh_tris[3 * (size_t)slot + 1], e2p = sc.bvh_tris[3 * (size_t)slot + 2];
+        n = normalize(cross(mk<T>(e1p.x, e1p.y, e1p.z), mk<T>(e2p.x, e2p.y, e2p.z)));   // :105-109
+        mi = (int)Bits<T>::to_u32(e1p.w);
     }
     const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
     Vec<T> diffuse = mk<T>(ma.x, ma.y, ma.z), emission = mk<T>(mb.x, mb.y, mb.z);
@@ -315,12 +404,12 @@ __device__ __forceinline__ Vec<T> segment_back(const Vec<T> pos, const Pending<T
 }
 
 // Whole segment by one lane (megakernel / trace kernels).
-template <class T>
+template <class T, bool BVH>
 __device__ __forceinline__ SegInfo trace_segment(const SceneLds<T> &sc, const RenderConst<T> &rc, Vec<T> &o, Vec<T> &d,
                                                  Vec<T> &beta, uint32_t pixel, uint32_t sample, uint32_t bounce,
                                                  bool scatter, Vec<T> &contrib, T &t_out) {
     Pending<T> pend;
-    SegInfo info = segment_front<T>(sc, o, d, beta, scatter, contrib, t_out, pend);
+    SegInfo info = segment_front<T, BVH>(sc, o, d, beta, scatter, contrib, t_out, pend);
     if (info.alive) {
         Vec<T> rnd = mk<T>(0, 0, 0);
         if (pend.kind == kDiffuse || pend.kind == kSpecRough)
@@ -410,7 +499,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 //   3. every lane: finish the directions; compaction by wave64 ballot + popcount prefix straight into
 //      the wave's region; survivors land in consecutive slots, so the 16-byte packet stores coalesce.
 // Results do not depend on which lane produced a random vector: it is a pure function of its key.
-template <class T, bool FIRST, int R>
+template <class T, bool FIRST, int R, bool BVH>
 __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
@@ -468,7 +557,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
                     q[r] = Bits<T>::to_u32(C.y);
                 }
                 Vec<T> contrib; T t_hit;
-                SegInfo si = segment_front<T>(sc, o[r], d, beta[r], scatter, contrib, t_hit, pend[r]);
+                SegInfo si = segment_front<T, BVH>(sc, o[r], d, beta[r], scatter, contrib, t_hit, pend[r]);
                 ++n_seg;
                 if (FIRST) {
                     Pack4<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z; l.w = 0;
@@ -561,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
 }
 
 // Megakernel: one thread walks one whole path in registers (the non-wavefront comparison point).
-template <class T>
+template <class T, bool BVH>
 __global__ __launch_bounds__(kBlock) void k_mega(const BounceArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
@@ -574,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(const BounceArgs<T> a) {
         camera_ray<T>(rc, pi, pj, pixel, sample, o, d);
         for (uint32_t b = 0; b < rc.max_depth; ++b) {
             Vec<T> contrib; T t_hit;
-            SegInfo si = trace_segment<T>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
+            SegInfo si = trace_segment<T, BVH>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
             ++nseg;
             if (b == 0) { if (si.has_contrib) Lacc = contrib; }
             else if (si.has_contrib) Lacc = Lacc + contrib;
@@ -589,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(const BounceArgs<T> a) {
 
 // Diagnostic: trace chosen paths and record every segment (prim, t, direction) — used by the
 // parity tests to compare path geometry bit for bit with the CPU restatement.
-template <class T>
+template <class T, bool BVH>
 __global__ __launch_bounds__(64) void k_trace(const BounceArgs<T> a, const uint32_t *ijs, uint32_t n_paths, int *prims, T *ts,
                                               T *dirs, T *radiance) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
@@ -604,7 +693,7 @@ __global__ __launch_bounds__(64) void k_trace(const BounceArgs<T> a, const uint3
     for (uint32_t b = 0; b < rc.max_depth; ++b) {
         Vec<T> contrib; T t_hit;
         Vec<T> dir_in = d;
-        SegInfo si = trace_segment<T>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
+        SegInfo si = trace_segment<T, BVH>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
         size_t k = (size_t)p * rc.max_depth + b;
         prims[k] = si.prim; ts[k] = t_hit;
         dirs[3 * k] = dir_in.x; dirs[3 * k + 1] = dir_in.y; dirs[3 * k + 2] = dir_in.z;

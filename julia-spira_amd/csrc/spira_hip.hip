@@ -19,6 +19,7 @@
 
 #include "../../include/spira_hip.h"
 #include "spira_device.h"
+#include "spira_bvh.h"
 
 
 namespace {
@@ -54,7 +55,8 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, scene, out_tmp, trace;
+    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, scene, out_tmp, trace, bvh_nodes, bvh_tris;
+    uint64_t bvh_hash = 0; uint32_t bvh_n = 0; int bvh_prec = 0, bvh_depth = 0;   // cached tree (keyed by the triangle bytes)
     spira::Stats *h_stats = nullptr;          // pinned
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<hipEvent_t> ev_pool;          // profile mode: pairs around bounce launches
@@ -118,9 +120,9 @@ int validate(const T *spheres5, const T *materials8, const T *triangles10, const
     if (p->max_depth > SPIRA_MAX_DEPTH) return fail(SPIRA_E_LIMIT, "max_depth > 255");
     if (p->n_materials < 1) return fail(SPIRA_E_INVALID, "n_materials must be >= 1");
     uint32_t nt = triangles10 ? p->n_triangles : 0;
-    if (p->n_spheres > SPIRA_MAX_LDS_SPHERES || nt > SPIRA_MAX_LDS_TRIANGLES)
-        return fail(SPIRA_E_LIMIT, "scene exceeds the LDS linear-scan limits (1024 spheres / 1024 triangles)");
-    if (spira::scene_lds_bytes<T>(p->n_spheres, p->n_materials, nt) > 150 * 1024)
+    if (p->n_spheres > SPIRA_MAX_LDS_SPHERES) return fail(SPIRA_E_LIMIT, "more than 1024 spheres");
+    if (nt > SPIRA_MAX_TRIANGLES) return fail(SPIRA_E_LIMIT, "more than 2^24 triangles");
+    if (spira::scene_lds_bytes<T>(p->n_spheres, p->n_materials, nt > SPIRA_LDS_TRIANGLES ? 0 : nt) > 120 * 1024)
         return fail(SPIRA_E_LIMIT, "scene does not fit in LDS");
     for (uint32_t i = 0; i < p->n_spheres; ++i) {
         T m = spheres5[5 * (size_t)i + 4];
@@ -181,12 +183,15 @@ bool fastdiv_selfcheck(uint32_t d, uint32_t n_max) {
     return true;
 }
 
-// Upload the flat scene arrays into one device buffer; returns device pointers in `g`.
+// Upload the flat scene arrays into one device buffer; returns device pointers in `g`.  Meshes above
+// SPIRA_LDS_TRIANGLES go through a BVH (built on the host once per distinct triangle array, cached).
 template <class T>
 int upload_scene(Ctx &c, hipStream_t st, const T *spheres5, const T *materials8, const T *triangles10, const spira_params *p,
                  spira::SceneGlobal<T> &g) {
     uint32_t nt = triangles10 ? p->n_triangles : 0;
-    size_t ns_b = (size_t)p->n_spheres * 5 * sizeof(T), nm_b = (size_t)p->n_materials * 8 * sizeof(T), nt_b = (size_t)nt * 10 * sizeof(T);
+    const bool use_bvh = nt > SPIRA_LDS_TRIANGLES;
+    const uint32_t nt_lds = use_bvh ? 0 : nt;
+    size_t ns_b = (size_t)p->n_spheres * 5 * sizeof(T), nm_b = (size_t)p->n_materials * 8 * sizeof(T), nt_b = (size_t)nt_lds * 10 * sizeof(T);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t total = up(ns_b) + up(nm_b) + up(nt_b) + 256;
     if (int rc = c.scene.ensure(total)) return rc;
@@ -194,20 +199,44 @@ int upload_scene(Ctx &c, hipStream_t st, const T *spheres5, const T *materials8,
     g.spheres5 = (const T *)base;
     g.materials8 = (const T *)(base + up(ns_b));
     g.triangles10 = (const T *)(base + up(ns_b) + up(nm_b));
-    g.n_spheres = p->n_spheres; g.n_materials = p->n_materials; g.n_triangles = nt;
+    g.n_spheres = p->n_spheres; g.n_materials = p->n_materials; g.n_triangles = nt_lds;
+    g.bvh_nodes = nullptr; g.bvh_tris = nullptr; g.n_bvh_tris = 0;
     if (ns_b) HIP_TRY(hipMemcpyAsync((void *)g.spheres5, spheres5, ns_b, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync((void *)g.materials8, materials8, nm_b, hipMemcpyHostToDevice, st));
     if (nt_b) HIP_TRY(hipMemcpyAsync((void *)g.triangles10, triangles10, nt_b, hipMemcpyHostToDevice, st));
+    if (use_bvh) {
+        const uint64_t h = spira::bytes_hash64(triangles10, (size_t)nt * 10 * sizeof(T));
+        if (c.bvh_hash != h || c.bvh_n != nt || c.bvh_prec != (int)sizeof(T)) {
+            std::vector<spira::HostPack4<T>> nodes, tris;
+            int depth = 0;
+            if (!spira::bvh_build<T>(triangles10, nt, nodes, tris, &depth)) return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
+            if (int rc = c.bvh_nodes.ensure(nodes.size() * sizeof(nodes[0]))) return rc;
+            if (int rc = c.bvh_tris.ensure(tris.size() * sizeof(tris[0]))) return rc;
+            // synchronous copies: the host vectors die at the end of this scope
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(c.bvh_nodes.p, nodes.data(), nodes.size() * sizeof(nodes[0]), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c.bvh_tris.p, tris.data(), tris.size() * sizeof(tris[0]), hipMemcpyHostToDevice));
+            c.bvh_hash = h; c.bvh_n = nt; c.bvh_prec = (int)sizeof(T); c.bvh_depth = depth;
+        }
+        g.bvh_nodes = (const spira::Pack4<T> *)c.bvh_nodes.p;
+        g.bvh_tris = (const spira::Pack4<T> *)c.bvh_tris.p;
+        g.n_bvh_tris = nt;
+    }
     return 0;
 }
 
+template <class T, bool FIRST, bool BVH>
+void launch_bounce_r(int R, dim3 grid, size_t lds, hipStream_t st, const spira::BounceArgs<T> &a) {
+    switch (R) {
+    case 4: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 4, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 2, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
+    default: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 1, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
+    }
+}
 template <class T, bool FIRST>
 void launch_bounce(int R, dim3 grid, size_t lds, hipStream_t st, const spira::BounceArgs<T> &a) {
-    switch (R) {
-    case 4: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 4>), grid, dim3(spira::kBlock), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 2>), grid, dim3(spira::kBlock), lds, st, a); break;
-    default: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 1>), grid, dim3(spira::kBlock), lds, st, a); break;
-    }
+    if (a.scene.n_bvh_tris) launch_bounce_r<T, FIRST, true>(R, grid, lds, st, a);
+    else launch_bounce_r<T, FIRST, false>(R, grid, lds, st, a);
 }
 
 int profile_events(Ctx &c, size_t need) {
@@ -316,7 +345,8 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
             uint32_t G = 0;
             if (mega) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
-                hipLaunchKernelGGL((spira::k_mega<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                if (a.scene.n_bvh_tris) hipLaunchKernelGGL((spira::k_mega<T, true>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                else hipLaunchKernelGGL((spira::k_mega<T, false>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 ++launches;
             } else {
                 geometry(n_first, G, a.cap);
@@ -406,7 +436,8 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     HIP_TRY(hipMemcpyAsync(d_ij, ijs, (size_t)n_paths * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_ts, 0, b_ts + b_di, st));
     const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + spira::kCompactScratchBytes;
-    hipLaunchKernelGGL((spira::k_trace<T>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    if (a.scene.n_bvh_tris) hipLaunchKernelGGL((spira::k_trace<T, true>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    else hipLaunchKernelGGL((spira::k_trace<T, false>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(prims, d_pr, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ts, d_ts, nseg * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -502,7 +533,7 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); }
-        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release();
+        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.bvh_nodes.release(); c.bvh_tris.release(); c.bvh_hash = 0; c.bvh_n = 0;
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
         (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop);

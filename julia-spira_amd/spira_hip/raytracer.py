@@ -92,16 +92,68 @@ def create_scene():
     return scene, camera
 
 
+def load_obj_mesh(filename, material, scale=None, rotation=None, translation=None, center=True, normalize_size=False):
+    """load_obj_mesh(filename, material; scale, rotation, translation, center, normalize_size) (:466-602).
+
+    Parses `v` and `f` records (first index of `a/b/c`, fan triangulation of n-gons :498-505), applies the
+    transform pipeline in the reference's order (scenes.transform_vertices) and returns the Triangle list."""
+    from .scenes import transform_vertices
+    vertices, faces = [], []
+    with open(filename, "r") as fh:
+        for line in fh:
+            if line.startswith("v "):                                   # :478-484
+                parts = line.split()
+                vertices.append((float(parts[1]), float(parts[2]), float(parts[3])))
+            elif line.startswith("f "):                                 # :485-505
+                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
+                if len(idx) == 3:
+                    faces.append(idx)
+                elif len(idx) > 3:
+                    for i in range(2, len(idx)):
+                        faces.append([idx[0], idx[i - 1], idx[i]])
+    v = transform_vertices(np.array(vertices, dtype=np.float64).reshape(-1, 3),
+                           scale=tuple(scale.tolist()) if scale is not None else (1.0, 1.0, 1.0),
+                           rotation=tuple(rotation.tolist()) if rotation is not None else (0.0, 0.0, 0.0),
+                           translation=tuple(translation.tolist()) if translation is not None else (0.0, 0.0, 0.0),
+                           center=center, normalize_size=normalize_size)
+    tris = []
+    for a, b, c in faces:                                               # 1-based OBJ indices (:490, :597)
+        tris.append(Triangle([Vec3(*v[a - 1]), Vec3(*v[b - 1]), Vec3(*v[c - 1])], material))
+    return tris
+
+
+def create_scene_with_obj(obj_file=None):
+    """create_scene_with_obj() (:644-706): ground + light + the OBJ mesh, or a sphere when the file is missing (:687-691)."""
+    import os
+    objects = [
+        Sphere(Vec3(0, -100.5, -1), 100, Material(diffuse=Vec3(0.8, 0.8, 0.2))),
+        Sphere(Vec3(0, 2, 0), 0.5, Material(diffuse=Vec3(0.8, 0.8, 0.8), emission=Vec3(4, 4, 4))),
+    ]
+    mesh_material = Material(diffuse=Vec3(0.7, 0.3, 0.2), specular=0.2, roughness=0.4)
+    obj_file = obj_file or os.path.expanduser("~/Downloads/bunny.obj")
+    if os.path.isfile(obj_file):
+        objects += load_obj_mesh(obj_file, mesh_material, center=True, normalize_size=True, scale=Vec3(0.5, 0.5, 0.5),
+                                 rotation=Vec3(0.0, 90.0, 0.0), translation=Vec3(0.0, 0.0, -1.0))
+    else:
+        print("OBJ file not found, adding a sphere instead")
+        objects.insert(2, Sphere(Vec3(0, 0, -1), 0.5, mesh_material))
+    scene = BoundingVolumeHierarchy(objects)
+    camera = Camera(position=Vec3(0.0, 1.0, 3.0), look_at=Vec3(0.0, 0.0, -1.0), up=Vec3(0.0, 1.0, 0.0), fov=45.0, aspect_ratio=16.0 / 9.0)
+    return scene, camera
+
+
 def flatten_world(world):
     """Hittable list -> the C-ABI flat arrays.  The ABI intersects spheres first, then triangles;
     a list that interleaves them differently is reordered only if that cannot change a result,
     i.e. never silently: mixed orders raise."""
-    spheres, tris, mats = [], [], []
+    spheres, tris, mats, mat_index = [], [], [], {}
     seen_triangle = False
     for obj in world.objects:
         m = obj.material
-        mats.append(m.diffuse.tolist() + m.emission.tolist() + [m.specular, m.roughness])
-        idx = len(mats)
+        if id(m) not in mat_index:        # one table entry per distinct Material object (a mesh shares one, :598)
+            mats.append(m.diffuse.tolist() + m.emission.tolist() + [m.specular, m.roughness])
+            mat_index[id(m)] = len(mats)
+        idx = mat_index[id(m)]
         if isinstance(obj, Sphere):
             if seen_triangle:
                 raise ValueError("the C ABI scans spheres before triangles; list spheres first")

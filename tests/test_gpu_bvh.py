@@ -1,0 +1,103 @@
+"""GPU (MI355X): triangle meshes through the device BVH must return exactly what the reference's linear
+closest-hit scan returns (examples/julia-raytracer.jl:213-258): bit-exact geometry against the oracle, which
+scans every triangle like the reference does; images to the north-star tolerance; ties go to the later triangle."""
+import numpy as np
+import pytest
+
+from spira_hip import scenes
+from test_gpu_parity import RTOL, ATOL, _args, _close, _counts, random_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _trace_equal(gpu, oracle, s, prec, W=160, H=90, spp=4, depth=6, n=3000, seed=17, window=None):
+    rng = np.random.default_rng(seed)
+    ns, nm, nt = _counts(s)
+    x0, x1, y0, y1 = window if window else (1, W + 1, 1, H + 1)      # 1-based pixel window the paths start in
+    ijs = np.stack([rng.integers(x0, x1, n), rng.integers(y0, y1, n), rng.integers(0, spp, n)], axis=1).astype(np.uint32)
+    prims, ts, dirs, rad = gpu.trace_paths(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=seed), ijs, prec)
+    po = oracle.make_params(W, H, spp, depth, ns, nm, nt, seed=seed)
+    tri_hits = 0
+    for k in range(n):
+        cnt, oprims, ots, odirs, orad = oracle.trace_path(*_args(s), po, int(ijs[k, 0]), int(ijs[k, 1]), int(ijs[k, 2]), prec)
+        oprims = np.where(np.arange(depth) < cnt, oprims, -2)
+        assert np.array_equal(prims[k], oprims), (k, prims[k], oprims)
+        assert np.array_equal(ts[k][:cnt].view(np.uint8), ots[:cnt].view(np.uint8)), (k, ts[k], ots)
+        assert np.array_equal(dirs[k][:cnt].view(np.uint8), odirs[:cnt].view(np.uint8)), k
+        tri_hits += int((oprims >= ns).sum())
+    return tri_hits
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_bvh_geometry_bit_exact_blob(gpu, oracle, prec):
+    s = scenes.scene_s4(level=3)          # 1280 triangles: the oracle scans them all per segment
+    assert _trace_equal(gpu, oracle, s, prec, window=(68, 94, 34, 58)) > 300      # paths aimed at the mesh
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_bvh_geometry_bit_exact_random_soup(gpu, oracle, prec):
+    rng = np.random.default_rng(5)
+    s = random_scene(rng, 12, 900, n_mats=7)     # intersecting, overlapping triangles + spheres
+    assert _trace_equal(gpu, oracle, s, prec, n=2500) > 500
+
+
+def test_bvh_ties_go_to_the_later_triangle(gpu, oracle):
+    """Duplicate every triangle (same vertices, different material): t is identical, the scan keeps the LATER one."""
+    rng = np.random.default_rng(9)
+    s = random_scene(rng, 0, 200, n_mats=6)
+    t = s["triangles10"]
+    dup = t.copy()
+    dup[:, 9] = (t[:, 9] % 6) + 1
+    order = rng.permutation(400)
+    both = np.concatenate([t, dup])[order]
+    s["triangles10"] = both
+    s["spheres5"] = np.zeros((0, 5))
+    _trace_equal(gpu, oracle, s, "f32", n=2000)
+    ns, nm, nt = _counts(s)
+    hdr, _ = gpu.render(*_args(s), gpu.make_params(96, 54, 4, 4, ns, nm, nt, seed=3), "f32")
+    ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(96, 54, 4, 4, ns, nm, nt, seed=3), "f32")
+    assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg
+
+
+@pytest.mark.parametrize("kernel", ["wavefront", "mega"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_bvh_image_matches_oracle(gpu, oracle, prec, kernel):
+    s = scenes.scene_s4(level=4)          # 5120 triangles
+    ns, nm, nt = _counts(s)
+    kflag = gpu.KERNEL_MEGA if kernel == "mega" else gpu.KERNEL_WAVEFRONT
+    hdr, _ = gpu.render(*_args(s), gpu.make_params(128, 72, 4, 5, ns, nm, nt, flags=kflag, seed=11), prec)
+    ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(128, 72, 4, 5, ns, nm, nt, seed=11), prec)
+    nbad, worst = _close(hdr, ohdr)
+    assert nbad == 0, (nbad, worst)
+    assert gpu.counters()["segments"] == oseg
+
+
+def test_bvh_threshold_boundary_and_cache(gpu, oracle):
+    """33 triangles take the BVH path, 32 the LDS scan: both must equal the oracle; changing the mesh between calls
+    must rebuild the cached tree."""
+    rng = np.random.default_rng(2)
+    for nt_ in (32, 33, 34):
+        s = random_scene(rng, 3, nt_)
+        ns, nm, nt = _counts(s)
+        hdr, _ = gpu.render(*_args(s), gpu.make_params(80, 45, 3, 4, ns, nm, nt, seed=1), "f32")
+        ohdr, _, _ = oracle.render(*_args(s), oracle.make_params(80, 45, 3, 4, ns, nm, nt, seed=1), "f32")
+        assert _close(hdr, ohdr)[0] == 0, nt_
+
+
+def test_config5_full_size_tiling_and_bunny_sized_mesh(gpu):
+    """BASELINE configs[4] shape: 81 920-triangle mesh + spheres, 1920x1080 depth 12 (spp reduced for test time):
+    finite image, the 8-way stripe tiling reproduces the untiled checksum, mega == wavefront."""
+    import zlib
+    from spira_hip import distributed as D
+    s = scenes.scene_s4(level=6)
+    ns, nm, nt = _counts(s)
+    W, H, spp, depth = 1920, 1080, 2, 12
+    a, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(5)), "f32")
+    assert np.isfinite(a).all() and a.min() >= 0
+    c = gpu.counters()
+    assert W * H * spp < c["segments"] <= W * H * spp * depth
+    tiles = [gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(5), **D.tile_params(H, 8, r, 8)), "f32")[0]
+             for r in range(8)]
+    assert zlib.crc32(D.assemble(tiles, H, 8, 8).tobytes()) == zlib.crc32(a.tobytes())
+    b, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.KERNEL_MEGA, seed=scenes.seed_for(5)), "f32")
+    assert np.array_equal(a, b)
