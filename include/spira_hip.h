@@ -119,6 +119,7 @@ typedef struct spira_counters {
     uint64_t segments;       /* path segments traced (ray/scene intersections)         */
     uint64_t rays_enqueued;  /* rays written to a queue (wavefront)                    */
     uint64_t radiance_rmw;   /* read-modify-writes of the per-path radiance (wavefront)*/
+    uint64_t radiance_stores;/* plain 16/32-byte stores of the per-path radiance          */
     uint64_t passes;         /* wavefront passes                                       */
     uint64_t launches;       /* kernel launches                                        */
     double   kernel_ms;      /* device time of the render, HIP events on the render stream */

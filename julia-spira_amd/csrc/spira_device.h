@@ -287,8 +287,12 @@ __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<
     const T a = dot(d, d);                                     // :115 (same value for every sphere)
     const T two_a = (T)2.0 * a;
     const T four_a = (T)4 * a;
+    // software-pipelined LDS reads: the next sphere's packet is requested before this one is tested, so the
+    // ds_read latency overlaps the arithmetic instead of stalling every iteration at s_waitcnt lgkmcnt(0)
+    Pack4<T> c_next = sc.sph[0];           // (slot 0 always exists in the LDS image: the block is never empty)
     for (uint32_t s = 0; s < sc.n_spheres; ++s) {
-        const Pack4<T> c = sc.sph[s];
+        const Pack4<T> c = c_next;
+        c_next = sc.sph[s + 1 < sc.n_spheres ? s + 1 : s];
         Vec<T> oc = o - mk<T>(c.x, c.y, c.z);                  // :114
         T b = (T)2.0 * dot(oc, d);                             // :116
         T cc = dot(oc, oc) - c.w;                              // :117
@@ -296,17 +300,24 @@ __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<
         if (!(disc < 0)) {                                     // :120
             T sq = sqrt_rn(disc);                              // :125
             T root = (-b - sq) / two_a;                        // :126
-            if (root < t_min || root > closest) {              // :130
+            bool ok = !(root < t_min || root > closest);       // :130
+            if (!ok) {
                 root = (-b + sq) / two_a;                      // :127,:131
-                if (root < t_min || root > closest) continue;  // :132
+                ok = !(root < t_min || root > closest);        // :132
             }
-            closest = root; prim = (int)s;                     // :137, :252
+            if (ok) { closest = root; prim = (int)s; }         // :137, :252
         }
     }
-    for (uint32_t i = 0; i < sc.n_triangles; ++i) {
-        T t;
-        if (triangle_test<T>(sc.tri[3 * i], sc.tri[3 * i + 1], sc.tri[3 * i + 2], o, d, t_min, closest, t)) {
-            closest = t; prim = (int)(sc.n_spheres + i);
+    if (sc.n_triangles) {
+        Pack4<T> v0n = sc.tri[0], e1n = sc.tri[1], e2n = sc.tri[2];
+        for (uint32_t i = 0; i < sc.n_triangles; ++i) {
+            const Pack4<T> v0 = v0n, e1 = e1n, e2 = e2n;
+            const uint32_t nx = i + 1 < sc.n_triangles ? i + 1 : i;
+            v0n = sc.tri[3 * nx]; e1n = sc.tri[3 * nx + 1]; e2n = sc.tri[3 * nx + 2];
+            T t;
+            if (triangle_test<T>(v0, e1, e2, o, d, t_min, closest, t)) {
+                closest = t; prim = (int)(sc.n_spheres + i);
+            }
         }
     }
     slot = 0;
@@ -346,6 +357,14 @@ __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &
     T t;
     uint32_t slot;
     int prim = closest_hit<T, BVH>(sc, o, d, (T)0.001, t, slot);             // :335
+#ifdef SPIRA_ABLATE_DOUBLE_HIT   // diagnostic build only: repeat the intersection on an opaque copy (is the kernel VALU-bound?)
+    {
+        Vec<T> o2 = o; T t2; uint32_t slot2;
+        asm volatile("" : "+v"(o2.x));
+        int prim2 = closest_hit<T, BVH>(sc, o2, d, (T)0.001, t2, slot2);
+        asm volatile("" ::"v"(prim2), "v"(t2));
+    }
+#endif
     info.prim = prim;
     t_out = prim >= 0 ? t : (T)0;
     pend.kind = kDead; pend.rough = 0; pend.v = mk<T>(0, 0, 0);
@@ -450,7 +469,7 @@ __device__ __forceinline__ void path_of(const RenderConst<T> &rc, uint32_t q, ui
 template <class T> struct RayQueue { Pack4<T> *A; Pack4<T> *B; Pack2<T> *C; };
 
 struct Stats {                       // device-side counters (one per context)
-    unsigned long long segments, rays_enqueued, radiance_rmw;
+    unsigned long long segments, rays_enqueued, radiance_rmw, radiance_store;
 };
 
 template <class T> struct BounceArgs {
@@ -460,7 +479,7 @@ template <class T> struct BounceArgs {
     Pack4<T> *L;                     // per-path radiance of the pass batch (slot-major), 16/32 B each
     const uint32_t *cnt_in;          // [NW] rays waiting in each wave's region of qin (bounce >= 1)
     uint32_t *cnt_out;               // [NW] survivors this bounce leaves in each region of qout
-    uint32_t *blk_stats;             // [NW][2] segments traced, radiance RMWs of this launch
+    uint32_t *blk_stats;             // [NW][4] segments traced, radiance RMWs, radiance stores of this launch
     uint32_t cap;                    // region size in rays (a multiple of R*64)
     Stats *stats;
     uint32_t bounce;
@@ -515,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
         for (uint32_t w = 0; w < WPB; ++w) n_blk += a.cnt_in[blockIdx.x * WPB + w];
         n_mine = a.cnt_in[wid];
         if (n_blk == 0) {                           // block-uniform: nothing left in this workgroup's regions
-            if (lane == 0) { if (scatter) a.cnt_out[wid] = 0; a.blk_stats[2 * wid] = 0; a.blk_stats[2 * wid + 1] = 0; }
+            if (lane == 0) { if (scatter) a.cnt_out[wid] = 0; a.blk_stats[4 * wid] = 0; a.blk_stats[4 * wid + 1] = 0; a.blk_stats[4 * wid + 2] = 0; }
             return;
         }
     }
@@ -524,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
     Pack4<T> *s_rnd = reinterpret_cast<Pack4<T> *>(lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles)) + wave * SUB;
     const uint32_t region = wid * a.cap;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t n_rmw = 0, n_seg = 0, fill = 0;
+    uint32_t n_rmw = 0, n_store = 0, n_seg = 0, fill = 0;
 
     const uint32_t limit = FIRST ? a.n_first : n_mine;
     const uint32_t n_sub = (limit + SUB - 1) / SUB;
@@ -534,6 +553,15 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
         uint32_t q[R], ent[R];
         uint32_t n_list = 0;
         // ---------------- phase 1
+        Pack4<T> inA[R], inB[R];
+        Pack2<T> inC[R];
+        if (!FIRST) {                  // all R rays' packet loads in flight before the first one is used
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t idx = sub * SUB + r * 64 + lane;
+                if (idx < limit) { inA[r] = a.qin.A[region + idx]; inB[r] = a.qin.B[region + idx]; inC[r] = a.qin.C[region + idx]; }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t idx = sub * SUB + r * 64 + lane;
@@ -549,8 +577,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
                     camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
                     beta[r] = mk<T>(1, 1, 1);
                 } else {
-                    const Pack4<T> A = a.qin.A[region + idx], B = a.qin.B[region + idx];
-                    const Pack2<T> C = a.qin.C[region + idx];
+                    const Pack4<T> A = inA[r], B = inB[r];
+                    const Pack2<T> C = inC[r];
                     o[r] = mk<T>(A.x, A.y, A.z);
                     d = mk<T>(A.w, B.x, B.y);
                     beta[r] = mk<T>(B.z, B.w, C.x);
@@ -559,19 +587,28 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
                 Vec<T> contrib; T t_hit;
                 SegInfo si = segment_front<T, BVH>(sc, o[r], d, beta[r], scatter, contrib, t_hit, pend[r]);
                 ++n_seg;
-                if (FIRST) {
+                // Path radiance L[q].  Bit 31 of the queued path index says "L[q] already holds radiance".  While it
+                // is clear a term is a plain 16-byte STORE (0 + x == x exactly): the load -> add -> store round trip,
+                // which parked every contributing wave for a full memory latency, only remains for paths that met
+                // an emitter earlier.  Every path stores exactly once more at its end (its last term, or zero).
+                // (No-return float atomics were tried instead: 30 % slower on S1 — scattered 4-byte atomics run at
+                // the memory side at ~1/17 of the coalesced rate, MI355X_MICROARCH.md.)
+                const uint32_t qi = q[r] & 0x7FFFFFFFu;
+                const bool has_l = (q[r] >> 31) != 0;
+                if (si.has_contrib) {
                     Pack4<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z; l.w = 0;
-                    if (!si.has_contrib) { l.x = 0; l.y = 0; l.z = 0; }
-                    a.L[q[r]] = l;
-                } else if (si.has_contrib) {
-                    Pack4<T> l = a.L[q[r]];
-                    l.x += contrib.x; l.y += contrib.y; l.z += contrib.z;
-                    a.L[q[r]] = l;
-                    ++n_rmw;
+                    if (has_l) { const Pack4<T> l0 = a.L[qi]; l.x = l0.x + contrib.x; l.y = l0.y + contrib.y; l.z = l0.z + contrib.z; ++n_rmw; }
+                    else ++n_store;
+                    a.L[qi] = l;
+                    q[r] |= 0x80000000u;
+                } else if (!si.alive && !has_l) {              // path ends without ever having contributed
+                    Pack4<T> l; l.x = 0; l.y = 0; l.z = 0; l.w = 0;
+                    a.L[qi] = l;
+                    ++n_store;
                 }
                 want = (pend[r].kind == kDiffuse || pend[r].kind == kSpecRough);
                 if (want) {
-                    if (!FIRST) path_of<T>(rc, q[r], a.pass, pi, pj, pixel, sample);
+                    if (!FIRST) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
                     key = rng_key(rc.sA, rc.sB, pixel, sample, a.bounce);
                 }
             }
@@ -641,11 +678,12 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
         wave_lds_sync();      // the list slots are rewritten by the next sub-chunk's phase 1
     }
     // per-wave results: survivors in the region, statistics (summed by k_resolve; no atomics)
-    for (int sft = 32; sft > 0; sft >>= 1) { n_rmw += __shfl_down(n_rmw, sft); n_seg += __shfl_down(n_seg, sft); }
+    for (int sft = 32; sft > 0; sft >>= 1) { n_rmw += __shfl_down(n_rmw, sft); n_seg += __shfl_down(n_seg, sft); n_store += __shfl_down(n_store, sft); }
     if (lane == 0) {
         if (scatter) a.cnt_out[wid] = fill;
-        a.blk_stats[2 * wid] = n_seg;
-        a.blk_stats[2 * wid + 1] = n_rmw;
+        a.blk_stats[4 * wid] = n_seg;
+        a.blk_stats[4 * wid + 1] = n_rmw;
+        a.blk_stats[4 * wid + 2] = n_store;
     }
 }
 
@@ -720,20 +758,21 @@ __global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack4
         accum[p] = acc;
     }
     if (blockIdx.x == 0 && blk_stats) {
-        __shared__ unsigned long long red[3];
-        if (threadIdx.x < 3) red[threadIdx.x] = 0;
+        __shared__ unsigned long long red[4];
+        if (threadIdx.x < 4) red[threadIdx.x] = 0;
         __syncthreads();
-        unsigned long long seg = 0, enq = 0, rmw = 0;
+        unsigned long long seg = 0, enq = 0, rmw = 0, sto = 0;
         for (uint32_t i = threadIdx.x; i < n_bounce * G; i += kBlock) {
-            const unsigned long long n = blk_stats[2 * i];
+            const unsigned long long n = blk_stats[4 * i];
             seg += n;
             if (i >= G) enq += n;                 // rays read from a queue == rays written to one
-            rmw += blk_stats[2 * i + 1];
+            rmw += blk_stats[4 * i + 1];
+            sto += blk_stats[4 * i + 2];
         }
-        for (int sft = 32; sft > 0; sft >>= 1) { seg += __shfl_down(seg, sft); enq += __shfl_down(enq, sft); rmw += __shfl_down(rmw, sft); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], seg); atomicAdd(&red[1], enq); atomicAdd(&red[2], rmw); }
+        for (int sft = 32; sft > 0; sft >>= 1) { seg += __shfl_down(seg, sft); enq += __shfl_down(enq, sft); rmw += __shfl_down(rmw, sft); sto += __shfl_down(sto, sft); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], seg); atomicAdd(&red[1], enq); atomicAdd(&red[2], rmw); atomicAdd(&red[3], sto); }
         __syncthreads();
-        if (threadIdx.x == 0) { stats->segments += red[0]; stats->rays_enqueued += red[1]; stats->radiance_rmw += red[2]; }
+        if (threadIdx.x == 0) { stats->segments += red[0]; stats->rays_enqueued += red[1]; stats->radiance_rmw += red[2]; stats->radiance_store += red[3]; }
     }
 }
 

@@ -300,7 +300,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     if (int rc = c.L.ensure(batch * sizeof(P4))) return rc;
     if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
     if (int rc = c.counts.ensure((size_t)(SPIRA_MAX_DEPTH + 2) * G_max * wpb * sizeof(uint32_t))) return rc;
-    if (int rc = c.blkstats.ensure((size_t)(SPIRA_MAX_DEPTH + 1) * G_max * wpb * 2 * sizeof(uint32_t))) return rc;
+    if (int rc = c.blkstats.ensure((size_t)(SPIRA_MAX_DEPTH + 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
     if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
 
     spira::BounceArgs<T> a{};
@@ -358,7 +358,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
                     a.qin = {(P4 *)c.qA[qi ^ 1].p, (P4 *)c.qB[qi ^ 1].p, (P2 *)c.qC[qi ^ 1].p};
                     a.cnt_in = (const uint32_t *)c.counts.p + (size_t)b * nw;
                     a.cnt_out = (uint32_t *)c.counts.p + (size_t)(b + 1) * nw;
-                    a.blk_stats = (uint32_t *)c.blkstats.p + (size_t)b * nw * 2;
+                    a.blk_stats = (uint32_t *)c.blkstats.p + (size_t)b * nw * 4;
                     if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                     const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4);   // + one work list per wave (one slot per ray of a sub-chunk)
                     if (b == 0) launch_bounce<T, true>(R, dim3(G), lds_b, st, a);
@@ -512,6 +512,7 @@ int spira_get_counters(spira_counters *out) {
         c.last.segments = c.h_stats->segments;
         c.last.rays_enqueued = c.h_stats->rays_enqueued;
         c.last.radiance_rmw = c.h_stats->radiance_rmw;
+        c.last.radiance_stores = c.h_stats->radiance_store;
         double bms = 0;
         for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
             float m = 0;
