@@ -742,6 +742,267 @@ __global__ __launch_bounds__(64) void k_trace(const BounceArgs<T> a, const uint3
     radiance[3 * p] = Lacc.x; radiance[3 * p + 1] = Lacc.y; radiance[3 * p + 2] = Lacc.z;
 }
 
+// ====================================================================== secondary integrator variants
+// Same scene/LDS/finalize machinery, different estimator.  Both run one lane per path (CPU variant) or per
+// pixel (METAL variant, whose RNG state is carried from sample to sample); spheres only, like their sources.
+template <class T> __device__ __forceinline__ Vec<T> sa_normalize(Vec<T> a) {     // StaticArrays: inv(norm(a)) * a
+    T inv = (T)1.0 / sqrt_rn(dot(a, a));
+    return mk<T>(inv * a.x, inv * a.y, inv * a.z);
+}
+
+// trace_ray of render_with_cpu, src/spira-metal-optimized.jl:1351-1412, iteratively:
+//   L = beta * (emission | sky) ends the path; beta *= albedo*0.5 (diffuse) | albedo (metallic).
+// Returns the number of segments; rec* (optional) record the per-segment trace.
+template <class T>
+__device__ __forceinline__ uint32_t path_cpu(const SceneLds<T> &sc, const RenderConst<T> &rc, uint32_t i, uint32_t j, uint32_t sample,
+                                             Vec<T> &L, int *rec_prims, T *rec_ts, T *rec_dirs) {
+    const uint32_t pixel = (j - 1) * rc.width + (i - 1);
+    T xu, xv, unused;
+    rng3<T>(rng_key(rc.sA, rc.sB, pixel, sample, 0), 0, xu, xv, unused);
+    T u = ((T)(i - 1) + xu) / (T)(rc.width - 1);                                    // :1428
+    T v = ((T)(j - 1) + xv) / (T)(rc.height - 1);                                   // :1429
+    Vec<T> o = rc.cam_origin;
+    Vec<T> d = sa_normalize(((rc.cam_llc + rc.cam_hor * u) + rc.cam_ver * v) - o);  // :1431-1432 (Ray ctor normalises, :297)
+    Vec<T> beta = mk<T>(1, 1, 1);
+    L = mk<T>(0, 0, 0);
+    uint32_t nseg = 0;
+    for (uint32_t b = 0; b < rc.max_depth; ++b) {                                   // depth <= 0 -> BLACK, :1352
+        ++nseg;
+        bool hit = false; int prim = -1, mi = 0;
+        T closest = (T)1e20f;                                                       // INF, :287
+        Vec<T> n = mk<T>(0, 0, 0);
+        for (uint32_t s = 0; s < sc.n_spheres; ++s) {                               // :1362-1385
+            const Pack4<T> c = sc.sph[s];
+            Vec<T> ctr = mk<T>(c.x, c.y, c.z);
+            Vec<T> oc = o - ctr;
+            T a = (T)1.0;                                                           // :1364
+            T half_b = dot(oc, d);
+            T cc = dot(oc, oc) - c.w;
+            T disc = half_b * half_b - a * cc;                                      // :1367
+            if (disc > 0) {
+                T sq = sqrt_rn(disc);
+                T root = (-half_b - sq) / a;                                        // :1373
+                if (root < (T)0.001f) root = (-half_b + sq) / a;                    // :1374-1376
+                if (root > (T)0.001f && root < closest) {                           // :1378
+                    closest = root; hit = true; prim = (int)s;
+                    n = sa_normalize((o + d * closest) - ctr);                      // :1381
+                    mi = sc.smat[s];
+                }
+            }
+        }
+        if (rec_prims) { rec_prims[b] = prim; rec_ts[b] = hit ? closest : (T)0; rec_dirs[3 * b] = d.x; rec_dirs[3 * b + 1] = d.y; rec_dirs[3 * b + 2] = d.z; }
+        if (!hit) {                                                                 // sky, :1411-1412
+            T ts = (T)0.5 * (d.y + (T)1.0);
+            L = mulv(beta, mk<T>(1, 1, 1) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts);
+            break;
+        }
+        const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
+        if (mb.x > 0 || mb.y > 0 || mb.z > 0) { L = mulv(beta, mk<T>(mb.x, mb.y, mb.z)); break; }   // :1392-1394: emitters end the path
+        if (b + 1 >= rc.max_depth) break;                                           // next level returns BLACK
+        const RngKey k = rng_key(rc.sA, rc.sB, pixel, sample, b);
+        T lobe, r0, r1, r2, u0_, u1_;
+        rng3<T>(k, 1, lobe, u0_, u1_);
+        rng3<T>(k, 2, r0, r1, r2);
+        const Vec<T> rv = mk<T>(r0, r1, r2) - mk<T>((T)0.5, (T)0.5, (T)0.5);        // rand(Vec3) - 0.5f0
+        const Vec<T> pos = o + d * closest;                                         // :1388
+        if (lobe > ma.w) {                                                          // rand > metallic -> diffuse, :1397
+            Vec<T> target = (pos + n) + sa_normalize(rv);                           // :1399
+            d = sa_normalize(sa_normalize(target - pos));                           // :1400 + Ray ctor
+            beta = mulv(mk<T>(ma.x, ma.y, ma.z), beta) * (T)0.5;                    // albedo .* L .* 0.5, :1401
+        } else {
+            Vec<T> reflected = d - n * ((T)2.0 * dot(d, n));                        // :1404
+            d = sa_normalize(sa_normalize(reflected + rv * mb.w));                  // :1405 + ctor
+            beta = mulv(mk<T>(ma.x, ma.y, ma.z), beta);                             // :1406
+        }
+        o = pos;
+    }
+    return nseg;
+}
+
+__device__ __forceinline__ float lcg_uniform(uint32_t &st, float) { st = st * 1664525u + 1013904223u; return (float)(st & 0x00FFFFFFu) / (float)0x01000000; }
+__device__ __forceinline__ double lcg_uniform(uint32_t &st, double) { st = st * 1664525u + 1013904223u; return (double)(st & 0x00FFFFFFu) / (double)0x01000000; }
+
+// sin/cos of 2*pi*r, r in [0,1): the same fixed polynomial, in the same plain arithmetic, as the oracle's.
+template <class T> __device__ __forceinline__ void sincos_turn(T r, T &sn, T &cs) {
+    T t = r * (T)4.0;
+    int k = (int)(t + (T)0.5);
+    T f = t - (T)k;
+    T th = f * (T)1.57079632679489661923;
+    T x2 = th * th;
+    const double SC[8] = {-1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0, -1.0 / 1307674368000.0,
+                          1.0 / 355687428096000.0};
+    const double CC[9] = {-1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600, -1.0 / 87178291200.0,
+                          1.0 / 20922789888000.0, -1.0 / 6402373705728000.0};
+    constexpr int ns = sizeof(T) == 4 ? 4 : 8, nc = sizeof(T) == 4 ? 5 : 9;
+    T ps = 0, pc = 0;
+#pragma unroll
+    for (int i = ns - 1; i >= 0; --i) ps = (ps + (T)SC[i]) * x2;
+#pragma unroll
+    for (int i = nc - 1; i >= 0; --i) pc = (pc + (T)CC[i]) * x2;
+    T s0 = th + th * ps, c0 = (T)1.0 + pc;
+    switch (k & 3) {
+    case 0: sn = s0; cs = c0; break;
+    case 1: sn = c0; cs = -s0; break;
+    case 2: sn = -s0; cs = -c0; break;
+    default: sn = -c0; cs = s0; break;
+    }
+}
+
+// One sample of path_trace, src/spira_path_trace_kernel.metal:140-269 (x, y = gid, 0-based, y = 0 is v = 0).
+template <class T>
+__device__ __forceinline__ uint32_t path_metal(const SceneLds<T> &sc, const RenderConst<T> &rc, uint32_t x, uint32_t y, uint32_t &st,
+                                               Vec<T> &acc, int *rec_prims, T *rec_ts, T *rec_dirs) {
+    const T EPSILON = (T)0.0001f, INF_ = (T)1e20f;                                  // :6-7
+    T xi = lcg_uniform(st, (T)0);
+    T u_j = ((T)x + xi) / (T)rc.width;                                              // :161
+    xi = lcg_uniform(st, (T)0);
+    T v_j = ((T)y + xi) / (T)rc.height;                                             // :162
+    Vec<T> o = rc.cam_origin;
+    Vec<T> d = normalize(((rc.cam_llc + rc.cam_hor * u_j) + rc.cam_ver * v_j) - o); // :167-170
+    Vec<T> thr = mk<T>(1, 1, 1);
+    acc = mk<T>(0, 0, 0);
+    uint32_t nseg = 0;
+    for (uint32_t depth = 0; depth < rc.max_depth; ++depth) {                       // :176
+        ++nseg;
+        T closest = INF_; int hit = -1; Vec<T> n = mk<T>(0, 0, 0);
+        for (uint32_t s = 0; s < sc.n_spheres; ++s) {                               // intersect_sphere, :109-136
+            const Pack4<T> c = sc.sph[s];
+            Vec<T> ctr = mk<T>(c.x, c.y, c.z);
+            Vec<T> oc = o - ctr;
+            T a = dot(d, d);
+            T half_b = dot(oc, d);
+            T cc = dot(oc, oc) - c.w;
+            T disc = half_b * half_b - a * cc;                                      // :117
+            T t = INF_; Vec<T> nn = mk<T>(0, 0, 0);
+            if (disc > (T)0.0) {
+                T sq = sqrt_rn(disc);
+                T root = (-half_b - sq) / a;                                        // :120
+                if (!(root > EPSILON)) root = (-half_b + sq) / a;                   // :127
+                if (root > EPSILON) { t = root; nn = normalize((o + d * t) - ctr); }   // :123 / :130
+            }
+            if (t < closest) { closest = t; hit = (int)s; n = nn; }                 // :184-188
+        }
+        if (rec_prims) { rec_prims[depth] = hit; rec_ts[depth] = hit >= 0 ? closest : (T)0; rec_dirs[3 * depth] = d.x; rec_dirs[3 * depth + 1] = d.y; rec_dirs[3 * depth + 2] = d.z; }
+        if (hit == -1) {                                                            // :192-198
+            T ts = (T)0.5 * (d.y + (T)1.0);
+            acc = acc + mulv(thr, mk<T>(1, 1, 1) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts);
+            break;
+        }
+        const int mi = sc.smat[hit];
+        const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
+        Vec<T> hit_point = o + d * closest;                                         // :203
+        if (dot(d, n) > (T)0.0) n = mk<T>(-n.x, -n.y, -n.z);                        // :207-209
+        acc = acc + mulv(thr, mk<T>(mb.x, mb.y, mb.z));                             // :212
+        Vec<T> scatter_origin = hit_point + n * EPSILON;                            // :215
+        Vec<T> nd;
+        xi = lcg_uniform(st, (T)0);
+        if (xi < ma.w) {                                                            // metal, :219
+            nd = d - n * ((T)2.0 * dot(d, n));                                      // reflect, :220
+            if (mb.w > (T)0.0) {                                                    // :221
+                Vec<T> pv = mk<T>(0, 0, 0);
+                for (int guard = 0; guard < 4096; ++guard) {                        // random_unit_vector, :61-70 (bounded: every wave must finish)
+                    T a0 = lcg_uniform(st, (T)0), a1 = lcg_uniform(st, (T)0), a2 = lcg_uniform(st, (T)0);
+                    pv = mk<T>(a0 * (T)2.0 - (T)1.0, a1 * (T)2.0 - (T)1.0, a2 * (T)2.0 - (T)1.0);
+                    if (dot(pv, pv) < (T)1.0) break;
+                }
+                nd = normalize(nd + normalize(pv) * mb.w);                          // :222
+            }
+        } else {                                                                    // cosine hemisphere, :73-93
+            T r1 = lcg_uniform(st, (T)0), r2 = lcg_uniform(st, (T)0), sn, cs;
+            sincos_turn<T>(r1, sn, cs);
+            T sr = sqrt_rn(r2);
+            T hx = cs * sr, hy = sn * sr;
+            T zz = (T)1.0 - hx * hx - hy * hy;
+            T hz = sqrt_rn(zz > (T)0.0 ? zz : (T)0.0);
+            Vec<T> helper = abs_t(n.x) > (T)0.1 ? mk<T>(0, 1, 0) : mk<T>(1, 0, 0);  // :89
+            Vec<T> ua = normalize(cross(helper, n));
+            Vec<T> va = cross(n, ua);
+            nd = normalize((ua * hx + va * hy) + n * hz);                           // :93
+        }
+        o = scatter_origin; d = nd;
+        thr = mulv(thr, mk<T>(ma.x, ma.y, ma.z));                                   // :232
+        if (depth > 3) {                                                            // :236-243
+            T pc = thr.x > thr.y ? thr.x : thr.y; pc = pc > thr.z ? pc : thr.z;
+            pc = pc < (T)0.95f ? pc : (T)0.95f;
+            xi = lcg_uniform(st, (T)0);
+            if (xi > pc) break;
+            thr = thr / pc;
+        }
+        { T mx = thr.x > thr.y ? thr.x : thr.y; mx = mx > thr.z ? mx : thr.z; if (mx < (T)0.01f) break; }   // :246
+    }
+    return nseg;
+}
+
+__device__ __forceinline__ uint32_t metal_state0(uint32_t sA, uint32_t sB, uint32_t pixel) { return mix32(mix32(sA + pixel) ^ sB); }
+
+// SEM 1 = render_with_cpu semantics: one lane per path, result into L (then k_resolve / k_finalize as usual).
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_variant_cpu(const BounceArgs<T> a) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    const RenderConst<T> &rc = a.rc;
+    unsigned long long nseg = 0;
+    for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < a.n_first; idx += gridDim.x * kBlock) {
+        uint32_t pixel, sample, pi, pj;
+        path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
+        Vec<T> Lp;
+        nseg += path_cpu<T>(sc, rc, pi, pj, sample, Lp, nullptr, nullptr, nullptr);
+        Pack4<T> l; l.x = Lp.x; l.y = Lp.y; l.z = Lp.z; l.w = 0;
+        a.L[idx] = l;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
+    if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
+}
+
+// SEM 2 = the .metal kernel's semantics: one lane per pixel walks all spp samples (its LCG state runs through
+// them, .metal :155/:268) and leaves their SUM in accum (the `output_hdr_image[p] += L` of :264).
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a, Pack4<T> *accum) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    const RenderConst<T> &rc = a.rc;
+    unsigned long long nseg = 0;
+    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < rc.tile_pixels; pl += gridDim.x * kBlock) {
+        uint32_t pixel, sample, pi, pj;
+        path_of<T>(rc, pl, 0, pi, pj, pixel, sample);
+        uint32_t st = metal_state0(rc.sA, rc.sB, pixel);
+        Vec<T> sum = mk<T>(0, 0, 0);
+        for (uint32_t s = 0; s < rc.spp; ++s) {
+            Vec<T> c;
+            nseg += path_metal<T>(sc, rc, pi - 1, pj - 1, st, c, nullptr, nullptr, nullptr);
+            sum = sum + c;
+        }
+        Pack4<T> l; l.x = sum.x; l.y = sum.y; l.z = sum.z; l.w = 0;
+        accum[pl] = l;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
+    if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
+}
+
+// Diagnostic trace for the secondary variants (same outputs as k_trace).
+template <class T, int SEM>
+__global__ __launch_bounds__(64) void k_trace_variant(const BounceArgs<T> a, const uint32_t *ijs, uint32_t n_paths, int *prims, T *ts,
+                                                      T *dirs, T *radiance) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    const RenderConst<T> &rc = a.rc;
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
+    uint32_t i = ijs[3 * p], j = ijs[3 * p + 1], sample = ijs[3 * p + 2];
+    int *pr = prims + (size_t)p * rc.max_depth;
+    T *pt = ts + (size_t)p * rc.max_depth, *pd = dirs + 3 * (size_t)p * rc.max_depth;
+    Vec<T> c = mk<T>(0, 0, 0);
+    uint32_t nseg = 0;
+    if (SEM == 1) {
+        nseg = path_cpu<T>(sc, rc, i, j, sample, c, pr, pt, pd);
+    } else {
+        uint32_t st = metal_state0(rc.sA, rc.sB, (j - 1) * rc.width + (i - 1));
+        for (uint32_t s = 0; s <= sample; ++s) nseg = path_metal<T>(sc, rc, i - 1, j - 1, st, c, pr, pt, pd);
+    }
+    for (uint32_t b = nseg; b < rc.max_depth; ++b) pr[b] = -2;
+    radiance[3 * p] = c.x; radiance[3 * p + 1] = c.y; radiance[3 * p + 2] = c.z;
+}
+
 // Per-pass resolve: accum[pix] += L[slot][pix] for slot = 0..k_eff-1, in sample order — the
 // `color = color + ray_color(...)` of examples/julia-raytracer.jl:401 in the same order.
 // Workgroup 0 also folds the pass's per-workgroup statistics [n_bounce][G][2] into the render totals.

@@ -134,7 +134,9 @@ int validate(const T *spheres5, const T *materials8, const T *triangles10, const
         if (!(m >= 1 && m <= (T)p->n_materials) || m != std::floor(m))
             return fail(SPIRA_E_INVALID, "triangle material index out of range");
     }
-    if ((p->flags & SPIRA_SEM_MASK) != SPIRA_SEM_A) return fail(SPIRA_E_UNSUPPORTED, "only SPIRA_SEM_A is implemented");
+    const uint32_t sem = p->flags & SPIRA_SEM_MASK;
+    if (sem != SPIRA_SEM_A && sem != SPIRA_SEM_CPU && sem != SPIRA_SEM_METAL) return fail(SPIRA_E_UNSUPPORTED, "unknown integrator semantics");
+    if (sem != SPIRA_SEM_A && nt) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_CPU / SPIRA_SEM_METAL are sphere-only, like their sources");
     uint32_t kern = p->flags & SPIRA_KERNEL_MASK;
     if (kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
     uint32_t rows = p->rows;
@@ -268,8 +270,10 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     if (slots64 * tile_pixels > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "tile too large: rows*width must be < 2^31");
     const uint32_t slots = (uint32_t)slots64;
     const uint64_t batch = slots64 * tile_pixels;
-    const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA;
-    const bool profile = (p->flags & SPIRA_FLAG_PROFILE) != 0;
+    const uint32_t sem = p->flags & SPIRA_SEM_MASK;
+    // the secondary variants run one lane per path / per pixel: no queues, no bounce kernels
+    const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA || sem != SPIRA_SEM_A;
+    const bool profile = (p->flags & SPIRA_FLAG_PROFILE) != 0 && !mega;
     int R = (int)env_u32("SPIRA_R", 2);
     if (R != 1 && R != 2 && R != 4) R = 2;
 
@@ -336,6 +340,12 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
 
     if (p->max_depth == 0) {
         HIP_TRY(hipMemsetAsync(c.accum.p, 0, tile_pixels * sizeof(P4), st));   // depth <= 0 -> Vec3(0,0,0), :330
+    } else if (sem == SPIRA_SEM_METAL) {
+        // one launch: every lane owns a pixel and walks its spp samples (the LCG state runs through them)
+        uint32_t blocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
+        a.pass = 0; a.n_first = (uint32_t)tile_pixels;
+        hipLaunchKernelGGL((spira::k_variant_metal<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p);
+        ++launches;
     } else {
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
             const uint32_t k_eff = std::min(slots, p->spp - pass * slots);
@@ -343,7 +353,11 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
             a.pass = pass;
             a.n_first = n_first;
             uint32_t G = 0;
-            if (mega) {
+            if (sem == SPIRA_SEM_CPU) {
+                uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
+                hipLaunchKernelGGL((spira::k_variant_cpu<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                ++launches;
+            } else if (mega) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
                 if (a.scene.n_bvh_tris) hipLaunchKernelGGL((spira::k_mega<T, true>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 else hipLaunchKernelGGL((spira::k_mega<T, false>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
@@ -436,7 +450,10 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     HIP_TRY(hipMemcpyAsync(d_ij, ijs, (size_t)n_paths * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_ts, 0, b_ts + b_di, st));
     const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + spira::kCompactScratchBytes;
-    if (a.scene.n_bvh_tris) hipLaunchKernelGGL((spira::k_trace<T, true>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    const uint32_t sem = p->flags & SPIRA_SEM_MASK;
+    if (sem == SPIRA_SEM_CPU) hipLaunchKernelGGL((spira::k_trace_variant<T, 1>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    else if (sem == SPIRA_SEM_METAL) hipLaunchKernelGGL((spira::k_trace_variant<T, 2>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    else if (a.scene.n_bvh_tris) hipLaunchKernelGGL((spira::k_trace<T, true>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
     else hipLaunchKernelGGL((spira::k_trace<T, false>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(prims, d_pr, nseg * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -117,26 +117,37 @@ def prepare_scene_data(scene):
     return sphere_data, material_data
 
 
-def render_hybrid_gpu(width, height, scene, camera, samples_per_pixel=16, max_depth=4, seed=0, post=B.POST_ACES_GAMMA,
-                      kernel=B.KERNEL_WAVEFRONT):
+SEMANTICS = {
+    "A": (B.SEM_A, B.POST_ACES_GAMMA),        # ray_color of examples/julia-raytracer.jl, K7 display transform (:1128-1144)
+    "cpu": (B.SEM_CPU, B.POST_CLAMP_GAMMA),   # trace_ray of render_with_cpu (:1346-1450): what render() runs on an AMD box today
+    "metal": (B.SEM_METAL, B.POST_ACES_GAMMA),  # path_trace of src/spira_path_trace_kernel.metal:140-269
+}
+
+
+def render_hybrid_gpu(width, height, scene, camera, samples_per_pixel=16, max_depth=4, seed=0, post=None,
+                      kernel=B.KERNEL_WAVEFRONT, semantics="A"):
     """render_hybrid_gpu(width, height, scene, camera; samples_per_pixel, max_depth) (:1228-1343).
 
     Returns an (H, W, 3) Float32 image, row 0 = image top (finalize_image_from_gpu_buffer :1157-1190),
-    after the display transform of K7 (:1128-1144).  `seed` is new: the reference never seeds.
+    after a display transform.  `seed` is new: the reference never seeds.  `semantics` picks which of the
+    reference's estimators runs (the host loop of :1274-1341 itself shades only the last bounce — a bug that is
+    not reproduced): "A" (default, the parity oracle), "cpu", "metal".
     """
     sphere_data, material_data = prepare_scene_data(scene)
+    sem, default_post = SEMANTICS[semantics]
     p = B.make_params(width, height, samples_per_pixel, max_depth, len(scene.spheres), len(scene.materials), 0,
-                      flags=B.SEM_A | kernel | post, seed=seed)
+                      flags=sem | kernel | (default_post if post is None else post), seed=seed)
     _, img = B.render(sphere_data, material_data, None, camera.flat(), p, prec="f32", want_hdr=False, want_img=True)
     return np.ascontiguousarray(np.moveaxis(img, 0, -1))
 
 
 def render(scene, camera, width, height, samples_per_pixel=16, max_depth=4, output_path="metal_optimized_render.png",
-           seed=0):
+           seed=0, semantics="A"):
     """render(scene, camera, width, height; samples_per_pixel=16, max_depth=4, output_path) (:1453-1490)."""
     start = time.time()
     print("Rendering with HIP GPU (MI355X, GPU-side accumulation)...")
-    img = render_hybrid_gpu(width, height, scene, camera, samples_per_pixel=samples_per_pixel, max_depth=max_depth, seed=seed)
+    img = render_hybrid_gpu(width, height, scene, camera, samples_per_pixel=samples_per_pixel, max_depth=max_depth, seed=seed,
+                            semantics=semantics)
     print("Render completed in %.2f seconds" % (time.time() - start))
     if output_path:
         save_png(output_path, img)

@@ -107,6 +107,51 @@ def trace_path(spheres5, materials8, triangles10, camera12, params, i, j, sample
     return n, prims, ts, dirs, rad
 
 
+def render_variant(spheres5, materials8, camera12, params, prec="f32", n_threads=0, want_img=False):
+    """SPIRA_SEM_CPU / SPIRA_SEM_METAL restatements (params.flags selects).  Returns (hdr, img or None, segments)."""
+    npdt, cdt, suf = _dt(prec)
+    s, sp = _arr(spheres5, npdt)
+    m, mp = _arr(materials8, npdt)
+    c, cp = _arr(camera12, npdt)
+    rows = params.rows if params.rows else params.height
+    hdr = np.empty((3, rows, params.width), dtype=npdt)
+    img = np.empty((3, rows, params.width), dtype=npdt) if want_img else None
+    seg = C.c_uint64(0)
+    fn = getattr(lib(), "oracle_render_variant" + suf)
+    fn.restype = C.c_int
+    rc = fn(sp, mp, cp, C.byref(params), hdr.ctypes.data_as(C.c_void_p), img.ctypes.data_as(C.c_void_p) if want_img else None,
+            C.c_int(n_threads), C.byref(seg))
+    if rc != 0:
+        raise RuntimeError("oracle_render_variant%s failed: %d" % (suf, rc))
+    return hdr, img, seg.value
+
+
+def trace_path_variant(spheres5, materials8, camera12, params, i, j, sample, prec="f32"):
+    npdt, cdt, suf = _dt(prec)
+    s, sp = _arr(spheres5, npdt)
+    m, mp = _arr(materials8, npdt)
+    c, cp = _arr(camera12, npdt)
+    d = params.max_depth
+    prims = np.zeros(d, dtype=np.int32)
+    ts = np.zeros(d, dtype=npdt)
+    dirs = np.zeros((d, 3), dtype=npdt)
+    rad = np.zeros(3, dtype=npdt)
+    fn = getattr(lib(), "oracle_trace_path_variant" + suf)
+    fn.restype = C.c_int
+    n = fn(sp, mp, cp, C.byref(params), C.c_uint32(i), C.c_uint32(j), C.c_uint32(sample), prims.ctypes.data_as(C.c_void_p),
+           ts.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p), rad.ctypes.data_as(C.c_void_p))
+    return n, prims, ts, dirs, rad
+
+
+def sincos_turn(r, prec="f64"):
+    npdt, cdt, suf = _dt(prec)
+    out = np.zeros(2, dtype=npdt)
+    fn = getattr(lib(), "oracle_sincos_turn" + suf)
+    fn.restype = None
+    fn(cdt(r), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def camera(position, look_at, up, fov_deg, aspect_ratio, focus_dist=1.0, prec="f64"):
     npdt, cdt, suf = _dt(prec)
     p, pp = _arr(position, npdt)

@@ -388,6 +388,292 @@ void SUF(oracle_rng_try)(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_
     SUF(rng3)(SUF(rng_key)(&w, pixel, sample, bounce), t, &u3[0], &u3[1], &u3[2]);
 }
 
+/* ======================================================================================== */
+/* Variant "CPU": trace_ray of render_with_cpu, src/spira-metal-optimized.jl:1346-1450.      */
+/* (What the reference's render() actually executes on an AMD machine today, :1469-1473.)    */
+/* Third-party arithmetic: StaticArrays (Project.toml:21 `StaticArrays = "1"`, unvendored):  */
+/* normalize(a) = inv(norm(a)) * a, norm = sqrt(sum(abs2)); restated below.  The reference    */
+/* draws from Julia's unseeded global RNG: the draws here are the build's counter-based RNG  */
+/* (try 0 = pixel jitter, try 1 = lobe choice, try 2 = rand(Vec3)).  PARITY UNPINNED.        */
+static inline V3 SUF(sa_normalize)(V3 a) {                     /* StaticArrays: inv(norm(a)) * a */
+    REAL inv = (REAL)1.0 / SQRT(SUF(dot)(a, a));
+    return SUF(v3)(inv * a.x, inv * a.y, inv * a.z);
+}
+
+static V3 SUF(trace_ray_cpu)(const World *w, Ray ray, int depth, uint32_t pixel, uint32_t sample, uint64_t *segments,
+                             TraceSeg *trace) {
+    if (depth <= 0) return SUF(v3)(0, 0, 0);                                        /* :1352-1354 */
+    uint32_t bounce = w->max_depth - (uint32_t)depth;
+    if (segments) ++*segments;
+    int hit_anything = 0, prim = -1, mat1 = 0;
+    REAL closest_t = (REAL)1e20f;                                                   /* INF = Float32(1e20), :287,:1357 */
+    V3 hit_normal = SUF(v3)(0, 0, 0);
+    for (uint32_t s = 0; s < w->n_spheres; ++s) {                                   /* :1362 */
+        const REAL *s5 = w->spheres5 + 5 * (size_t)s;
+        V3 center = SUF(v3)(s5[0], s5[1], s5[2]);
+        V3 oc = SUF(sub)(ray.origin, center);                                       /* :1363 */
+        REAL a = (REAL)1.0;                                                         /* :1364 */
+        REAL half_b = SUF(dot)(oc, ray.direction);                                  /* :1365 */
+        REAL c = SUF(dot)(oc, oc) - s5[3] * s5[3];                                  /* :1366 */
+        REAL discriminant = half_b * half_b - a * c;                                /* :1367 */
+        if (discriminant > 0) {                                                     /* :1369 */
+            REAL sqrtd = SQRT(discriminant);
+            REAL root = (-half_b - sqrtd) / a;                                      /* :1373 */
+            if (root < (REAL)0.001f) root = (-half_b + sqrtd) / a;                  /* :1374-1376 */
+            if (root > (REAL)0.001f && root < closest_t) {                          /* :1378 */
+                closest_t = root; hit_anything = 1; prim = (int)s;
+                hit_normal = SUF(sa_normalize)(SUF(sub)(SUF(add)(ray.origin, SUF(scale)(ray.direction, closest_t)), center)); /* :1381 */
+                mat1 = (int)s5[4];
+            }
+        }
+    }
+    if (trace) {
+        trace[bounce].prim = prim; trace[bounce].t = hit_anything ? closest_t : (REAL)0;
+        trace[bounce].dir[0] = ray.direction.x; trace[bounce].dir[1] = ray.direction.y; trace[bounce].dir[2] = ray.direction.z;
+    }
+    if (hit_anything) {
+        V3 hit_point = SUF(add)(ray.origin, SUF(scale)(ray.direction, closest_t));  /* :1388 */
+        Material m = SUF(get_material)(w, mat1);
+        if (m.emission.x > 0 || m.emission.y > 0 || m.emission.z > 0) return m.emission;   /* :1392-1394: the path ends */
+        RngKey k = SUF(rng_key)(w, pixel, sample, bounce);
+        REAL lobe, r0, r1, r2, unused0, unused1;
+        SUF(rng3)(k, 1, &lobe, &unused0, &unused1);
+        SUF(rng3)(k, 2, &r0, &r1, &r2);
+        V3 rv = SUF(sub)(SUF(v3)(r0, r1, r2), SUF(v3)((REAL)0.5, (REAL)0.5, (REAL)0.5));   /* rand(Vec3) - 0.5f0 */
+        Ray scattered; scattered.origin = hit_point;
+        if (lobe > m.specular) {                                                    /* rand(Float32) > material.metallic, :1397 */
+            V3 target = SUF(add)(SUF(add)(hit_point, hit_normal), SUF(sa_normalize)(rv));   /* :1399 */
+            scattered.direction = SUF(sa_normalize)(SUF(sa_normalize)(SUF(sub)(target, hit_point)));   /* :1400 + Ray ctor :297 */
+            V3 in = SUF(trace_ray_cpu)(w, scattered, depth - 1, pixel, sample, segments, trace);
+            return SUF(scale)(SUF(mulv)(m.diffuse, in), (REAL)0.5);                 /* albedo .* L .* 0.5, :1401 */
+        } else {
+            V3 reflected = SUF(sub)(ray.direction, SUF(scale)(hit_normal, (REAL)2.0 * SUF(dot)(ray.direction, hit_normal)));  /* :1404 */
+            scattered.direction = SUF(sa_normalize)(SUF(sa_normalize)(SUF(add)(reflected, SUF(scale)(rv, m.roughness))));   /* :1405 + ctor */
+            V3 in = SUF(trace_ray_cpu)(w, scattered, depth - 1, pixel, sample, segments, trace);
+            return SUF(mulv)(m.diffuse, in);                                        /* :1406 */
+        }
+    }
+    REAL t = (REAL)0.5 * (ray.direction.y + (REAL)1.0);                             /* :1411 */
+    return SUF(add)(SUF(scale)(SUF(v3)(1, 1, 1), (REAL)1.0 - t), SUF(scale)(SUF(v3)((REAL)0.5, (REAL)0.7, (REAL)1.0), t));   /* :1412 */
+}
+
+static V3 SUF(sample_pixel_cpu)(const World *w, const spira_params *p, uint32_t i, uint32_t j, uint32_t sample,
+                                uint64_t *segments, TraceSeg *trace) {
+    uint32_t pixel = (j - 1) * p->width + (i - 1);
+    REAL xi_u, xi_v, unused;
+    SUF(rng3)(SUF(rng_key)(w, pixel, sample, 0), 0, &xi_u, &xi_v, &unused);
+    REAL u = ((REAL)(i - 1) + xi_u) / (REAL)(p->width - 1);                         /* :1428 */
+    REAL v = ((REAL)(j - 1) + xi_v) / (REAL)(p->height - 1);                        /* :1429 */
+    V3 dir = SUF(sub)(SUF(add)(SUF(add)(w->cam_llc, SUF(scale)(w->cam_hor, u)), SUF(scale)(w->cam_ver, v)), w->cam_origin);  /* :1431 */
+    Ray ray; ray.origin = w->cam_origin; ray.direction = SUF(sa_normalize)(dir);    /* Ray ctor, :1432 */
+    return SUF(trace_ray_cpu)(w, ray, (int)p->max_depth, pixel, sample, segments, trace);   /* :1434 */
+}
+
+/* ======================================================================================== */
+/* Variant "METAL": path_trace of src/spira_path_trace_kernel.metal:140-269 (+ helpers       */
+/* :52-136).  The file is HTML-escaped and nothing loads it; this restates what  */
+/* it says, in IEEE arithmetic in the written order (Metal's fast-math is unknowable).       */
+/* RNG: the kernel's own LCG (:52-58), state per pixel carried from sample to sample (:268); */
+/* the initial states, which the reference's host would draw at random, come from the seed.  */
+/* sin/cos: a fixed polynomial evaluated in plain arithmetic (the kernels use the same one). */
+static inline uint32_t SUF(lcg_uniform)(uint32_t *state, REAL *u) {
+    *state = *state * 1664525u + 1013904223u;                                       /* :55-56 */
+    *u = (REAL)(*state & 0x00FFFFFFu) / (REAL)0x01000000;                           /* :57 */
+    return *state;
+}
+
+/* sin(2*pi*r), cos(2*pi*r) for r in [0,1): nearest quarter turn k, remainder f in [-1/2,1/2] quarter turns,
+ * theta = f*(pi/2) in [-pi/4, pi/4], Taylor polynomials in theta^2 (Horner), then rotate by k quadrants. */
+static inline void SUF(sincos_turn)(REAL r, REAL *sn, REAL *cs) {
+    REAL t = r * (REAL)4.0;
+    int k = (int)(t + (REAL)0.5);
+    REAL f = t - (REAL)k;
+    REAL th = f * (REAL)1.57079632679489661923;
+    REAL x2 = th * th;
+    REAL ps = 0, pc = 0;
+    static const double SC[8] = { -1.0 / 6, 1.0 / 120, -1.0 / 5040, 1.0 / 362880, -1.0 / 39916800, 1.0 / 6227020800.0,
+                                  -1.0 / 1307674368000.0, 1.0 / 355687428096000.0 };
+    static const double CC[9] = { -1.0 / 2, 1.0 / 24, -1.0 / 720, 1.0 / 40320, -1.0 / 3628800, 1.0 / 479001600, -1.0 / 87178291200.0,
+                                  1.0 / 20922789888000.0, -1.0 / 6402373705728000.0 };
+    const int ns = sizeof(REAL) == 4 ? 4 : 8, nc = sizeof(REAL) == 4 ? 5 : 9;
+    for (int i = ns - 1; i >= 0; --i) ps = (ps + (REAL)SC[i]) * x2;
+    for (int i = nc - 1; i >= 0; --i) pc = (pc + (REAL)CC[i]) * x2;
+    REAL s0 = th + th * ps, c0 = (REAL)1.0 + pc;
+    switch (k & 3) {
+    case 0: *sn = s0; *cs = c0; break;
+    case 1: *sn = c0; *cs = -s0; break;
+    case 2: *sn = -s0; *cs = -c0; break;
+    default: *sn = -c0; *cs = s0; break;
+    }
+}
+
+static V3 SUF(sample_pixel_metal)(const World *w, const spira_params *p, uint32_t x, uint32_t y, uint32_t *rng_state,
+                                  uint64_t *segments, TraceSeg *trace) {
+    const REAL EPSILON = (REAL)0.0001f, INF_ = (REAL)1e20f;                         /* :6-7 */
+    uint32_t st = *rng_state;                                                       /* :155 */
+    REAL xi;
+    SUF(lcg_uniform)(&st, &xi);
+    REAL u_j = ((REAL)x + xi) / (REAL)p->width;                                     /* :161 */
+    SUF(lcg_uniform)(&st, &xi);
+    REAL v_j = ((REAL)y + xi) / (REAL)p->height;                                    /* :162 */
+    V3 o = w->cam_origin;                                                           /* :166 */
+    V3 d = SUF(normalize)(SUF(sub)(SUF(add)(SUF(add)(w->cam_llc, SUF(scale)(w->cam_hor, u_j)), SUF(scale)(w->cam_ver, v_j)), o)); /* :167-170 */
+    V3 acc = SUF(v3)(0, 0, 0), thr = SUF(v3)(1, 1, 1);                              /* :173-174 */
+    for (uint32_t depth = 0; depth < p->max_depth; ++depth) {                       /* :176 */
+        if (segments) ++*segments;
+        REAL closest_t = INF_; int hit = -1; V3 n = SUF(v3)(0, 0, 0);               /* :177-179 */
+        for (uint32_t s = 0; s < w->n_spheres; ++s) {                               /* :182 */
+            const REAL *s5 = w->spheres5 + 5 * (size_t)s;                           /* intersect_sphere, :109-136 */
+            V3 center = SUF(v3)(s5[0], s5[1], s5[2]);
+            V3 oc = SUF(sub)(o, center);                                            /* :113 */
+            REAL a = SUF(dot)(d, d);                                                /* :114 */
+            REAL half_b = SUF(dot)(oc, d);                                          /* :115 */
+            REAL c = SUF(dot)(oc, oc) - s5[3] * s5[3];                              /* :116 */
+            REAL disc = half_b * half_b - a * c;                                    /* :117 */
+            REAL t = INF_; V3 nn = SUF(v3)(0, 0, 0);
+            if (disc > (REAL)0.0) {                                                 /* :119 */
+                REAL sq = SQRT(disc);
+                REAL root = (-half_b - sq) / a;                                     /* :120 */
+                if (!(root > EPSILON)) root = (-half_b + sq) / a;                   /* :121,:127 */
+                if (root > EPSILON) {                                               /* :128 */
+                    t = root;
+                    nn = SUF(normalize)(SUF(sub)(SUF(add)(o, SUF(scale)(d, t)), center));   /* :123/:130 */
+                }
+            }
+            if (t < closest_t) { closest_t = t; hit = (int)s; n = nn; }            /* :184-188: strict <, the earlier sphere keeps a tie */
+        }
+        if (trace) {
+            trace[depth].prim = hit; trace[depth].t = hit >= 0 ? closest_t : (REAL)0;
+            trace[depth].dir[0] = d.x; trace[depth].dir[1] = d.y; trace[depth].dir[2] = d.z;
+        }
+        if (hit == -1) {                                                            /* :192 */
+            REAL ts = (REAL)0.5 * (d.y + (REAL)1.0);                                /* :194 */
+            V3 sky = SUF(add)(SUF(scale)(SUF(v3)(1, 1, 1), (REAL)1.0 - ts), SUF(scale)(SUF(v3)((REAL)0.5, (REAL)0.7, (REAL)1.0), ts)); /* :195 */
+            acc = SUF(add)(acc, SUF(mulv)(thr, sky));                               /* :196 */
+            break;
+        }
+        Material m = SUF(get_material)(w, (int)w->spheres5[5 * (size_t)hit + 4]);   /* :202 */
+        V3 hit_point = SUF(add)(o, SUF(scale)(d, closest_t));                       /* :203 */
+        if (SUF(dot)(d, n) > (REAL)0.0) n = SUF(v3)(-n.x, -n.y, -n.z);              /* :207-209 */
+        acc = SUF(add)(acc, SUF(mulv)(thr, m.emission));                            /* :212 */
+        V3 scatter_origin = SUF(add)(hit_point, SUF(scale)(n, EPSILON));            /* :215 */
+        V3 nd;
+        SUF(lcg_uniform)(&st, &xi);
+        if (xi < m.specular) {                                                      /* random_uniform < metallic, :219 */
+            nd = SUF(sub)(d, SUF(scale)(n, (REAL)2.0 * SUF(dot)(d, n)));            /* reflect, :96-98, :220 */
+            if (m.roughness > (REAL)0.0) {                                          /* :221 */
+                V3 pv;
+                for (;;) {                                                          /* random_unit_vector, :61-70 */
+                    REAL a0, a1, a2;
+                    SUF(lcg_uniform)(&st, &a0); SUF(lcg_uniform)(&st, &a1); SUF(lcg_uniform)(&st, &a2);
+                    pv = SUF(v3)(a0 * (REAL)2.0 - (REAL)1.0, a1 * (REAL)2.0 - (REAL)1.0, a2 * (REAL)2.0 - (REAL)1.0);
+                    if (SUF(dot)(pv, pv) < (REAL)1.0) break;
+                }
+                nd = SUF(normalize)(SUF(add)(nd, SUF(scale)(SUF(normalize)(pv), m.roughness)));   /* :222 */
+            }
+        } else {                                                                    /* cosine hemisphere, :73-93 */
+            REAL r1, r2, sn, cs;
+            SUF(lcg_uniform)(&st, &r1); SUF(lcg_uniform)(&st, &r2);
+            SUF(sincos_turn)(r1, &sn, &cs);                                         /* phi = 2*pi*r1, :77 */
+            REAL sr = SQRT(r2);
+            REAL hx = cs * sr, hy = sn * sr;                                        /* :83-84 */
+            REAL zz = (REAL)1.0 - hx * hx - hy * hy;
+            REAL hz = SQRT(zz > (REAL)0.0 ? zz : (REAL)0.0);                        /* :85 */
+            V3 helper = FABS(n.x) > (REAL)0.1 ? SUF(v3)(0, 1, 0) : SUF(v3)(1, 0, 0);   /* :89 */
+            V3 ua = SUF(normalize)(SUF(cross)(helper, n));                          /* :90 */
+            V3 va = SUF(cross)(n, ua);                                              /* :91 */
+            nd = SUF(normalize)(SUF(add)(SUF(add)(SUF(scale)(ua, hx), SUF(scale)(va, hy)), SUF(scale)(n, hz)));   /* :93 */
+        }
+        o = scatter_origin; d = nd;                                                 /* :230-231 */
+        thr = SUF(mulv)(thr, m.diffuse);                                            /* :232 */
+        if (depth > 3) {                                                            /* Russian roulette, :236-243 */
+            REAL pc = thr.x > thr.y ? thr.x : thr.y; pc = pc > thr.z ? pc : thr.z;
+            pc = pc < (REAL)0.95f ? pc : (REAL)0.95f;
+            SUF(lcg_uniform)(&st, &xi);
+            if (xi > pc) break;
+            thr = SUF(divs)(thr, pc);
+        }
+        { REAL mx = thr.x > thr.y ? thr.x : thr.y; mx = mx > thr.z ? mx : thr.z; if (mx < (REAL)0.01f) break; }   /* :246 */
+    }
+    *rng_state = st;                                                                /* :268 */
+    return acc;
+}
+
+/* initial per-pixel LCG state (the reference's host would fill rng_states with random UInt32s, cf.
+ * src/spira-metal-optimized.jl:1258): derived from the seed */
+static inline uint32_t SUF(metal_state0)(const World *w, uint32_t pixel) { return oracle_mix32(oracle_mix32(w->sA + pixel) ^ w->sB); }
+
+/* Render with one of the secondary variants (flags & SPIRA_SEM_MASK = SPIRA_SEM_CPU | SPIRA_SEM_METAL). */
+int SUF(oracle_render_variant)(const REAL *spheres5, const REAL *materials8, const REAL *camera12, const spira_params *p,
+                               REAL *out_hdr, REAL *out_img, int n_threads, uint64_t *segments_out) {
+    if (!spheres5 || !materials8 || !camera12 || !p) return -1;
+    const uint32_t sem = p->flags & SPIRA_SEM_MASK;
+    if (sem != SPIRA_SEM_CPU && sem != SPIRA_SEM_METAL) return -5;
+    World w; SUF(world_init)(&w, spheres5, materials8, NULL, camera12, p);
+    uint32_t W = p->width, H = p->height;
+    uint32_t rows = p->rows ? p->rows : H;
+    size_t plane = (size_t)rows * W;
+    uint32_t post = p->flags & SPIRA_POST_MASK;
+    uint64_t segments = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : segments)
+#endif
+    for (uint32_t r = 0; r < rows; ++r) {
+        uint32_t y = p->rows ? oracle_global_row(p, r) : r;
+        uint32_t j = (p->flags & SPIRA_ROWS_BOTTOM_UP) ? y + 1 : H - y;      /* j = 1 is v = 0 (gid.y = 0 in the .metal kernel) */
+        for (uint32_t i = 1; i <= W; ++i) {
+            V3 color = SUF(v3)(0, 0, 0);
+            uint32_t pixel = (j - 1) * W + (i - 1);
+            uint32_t st = SUF(metal_state0)(&w, pixel);
+            for (uint32_t s = 0; s < p->spp; ++s) {
+                V3 c = sem == SPIRA_SEM_CPU ? SUF(sample_pixel_cpu)(&w, p, i, j, s, &segments, NULL)
+                                            : SUF(sample_pixel_metal)(&w, p, i - 1, j - 1, &st, &segments, NULL);
+                color = SUF(add)(color, c);                                   /* :1434 / .metal :264 */
+            }
+            color = SUF(divs)(color, (REAL)p->spp);                           /* :1438 */
+            size_t o = (size_t)r * W + (i - 1);
+            if (out_hdr) { out_hdr[o] = color.x; out_hdr[plane + o] = color.y; out_hdr[2 * plane + o] = color.z; }
+            if (out_img) {
+                out_img[o] = SUF(post1)(color.x, post); out_img[plane + o] = SUF(post1)(color.y, post);
+                out_img[2 * plane + o] = SUF(post1)(color.z, post);
+            }
+        }
+    }
+    if (segments_out) *segments_out = segments;
+    return 0;
+}
+
+/* Trace one path of a secondary variant (METAL: the `sample`-th path of the pixel, replaying the earlier ones
+ * to reach its RNG state).  Same outputs as oracle_trace_path. */
+int SUF(oracle_trace_path_variant)(const REAL *spheres5, const REAL *materials8, const REAL *camera12, const spira_params *p,
+                                   uint32_t i, uint32_t j, uint32_t sample, int *prims, REAL *ts, REAL *dirs3, REAL *radiance3) {
+    const uint32_t sem = p->flags & SPIRA_SEM_MASK;
+    World w; SUF(world_init)(&w, spheres5, materials8, NULL, camera12, p);
+    TraceSeg tr[256];
+    uint64_t segs = 0;
+    V3 c;
+    if (sem == SPIRA_SEM_CPU) {
+        for (uint32_t b = 0; b < 256; ++b) { tr[b].prim = -2; tr[b].t = 0; tr[b].dir[0] = tr[b].dir[1] = tr[b].dir[2] = 0; }
+        c = SUF(sample_pixel_cpu)(&w, p, i, j, sample, &segs, tr);
+    } else {
+        uint32_t st = SUF(metal_state0)(&w, (j - 1) * p->width + (i - 1));
+        for (uint32_t s = 0; s <= sample; ++s) {
+            for (uint32_t b = 0; b < 256; ++b) { tr[b].prim = -2; tr[b].t = 0; tr[b].dir[0] = tr[b].dir[1] = tr[b].dir[2] = 0; }
+            segs = 0;
+            c = SUF(sample_pixel_metal)(&w, p, i - 1, j - 1, &st, &segs, tr);
+        }
+    }
+    for (uint32_t b = 0; b < p->max_depth; ++b) {
+        prims[b] = tr[b].prim; ts[b] = tr[b].t;
+        dirs3[3 * b] = tr[b].dir[0]; dirs3[3 * b + 1] = tr[b].dir[1]; dirs3[3 * b + 2] = tr[b].dir[2];
+    }
+    radiance3[0] = c.x; radiance3[1] = c.y; radiance3[2] = c.z;
+    return (int)segs;
+}
+
+void SUF(oracle_sincos_turn)(REAL r, REAL *sc2) { SUF(sincos_turn)(r, &sc2[0], &sc2[1]); }
+
 #undef V3
 #undef Material
 #undef HitRecord

@@ -1,0 +1,63 @@
+"""GPU (MI355X): the host-side mirrors called the way the reference's own scripts and tests call the reference.
+
+tests/test-tiny.jl:9-38            128x72  spp1  depth1 through render(scene, camera, W, H; ...)
+tests/test-metal-optimized.jl:9-38 320x180 spp4  depth2
+examples/basic_render.jl:15-35     640x360 spp16 depth4
+tests/bunny-test.jl:37-60          64x64 spp1 (the only assertion of the reference: size(image) == (64, 64))
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_and_camera(width, height):
+    import spira_hip as S
+    aspect = np.float32(width / height)
+    cam = S.Camera(S.Point3(0.0, 1.0, 3.0), S.Point3(0.0, 0.0, 0.0), S.Vec3(0.0, 1.0, 0.0), np.float32(40.0), aspect)
+    return S.create_scene(), cam
+
+
+@pytest.mark.parametrize("w,h,spp,depth", [(128, 72, 1, 1), (320, 180, 4, 2), (640, 360, 16, 4)])
+def test_reference_script_call_shapes(gpu, oracle, tmp_path, w, h, spp, depth):
+    import spira_hip as S
+    scene, cam = _scene_and_camera(w, h)
+    out = str(tmp_path / "render.png")
+    img = S.render(scene, cam, w, h, samples_per_pixel=spp, max_depth=depth, output_path=out, seed=1)
+    assert img.shape == (h, w, 3) and img.dtype == np.float32 and img.min() >= 0 and img.max() <= 1
+    assert os.path.getsize(out) > 1000 and open(out, "rb").read(4) == b"\x89PNG"
+    assert img[0].mean() > img[-1].mean() * 0.5 and img[0, :, 2].mean() > 0.9      # row 0 is the sky (top), blue channel ~1
+    # the same call through the flat ABI arrays equals the oracle (semantics A + ACES/sqrt display transform)
+    sd, md = S.prepare_scene_data(scene)
+    ohdr, oimg, _ = oracle.render(sd.reshape(-1, 5), md.reshape(-1, 8), None, cam.flat(),
+                                  oracle.make_params(w, h, spp, depth, 5, 5, 0, flags=0x100, seed=1), "f32", want_img=True)
+    assert np.allclose(img, np.moveaxis(oimg, 0, -1), rtol=1e-5, atol=1e-6)
+    for sem in ("cpu", "metal"):
+        alt = S.render(scene, cam, w, h, samples_per_pixel=spp, max_depth=depth, output_path="", seed=1, semantics=sem)
+        assert alt.shape == (h, w, 3) and np.isfinite(alt).all()
+
+
+def test_bunny_test_shape_and_oracle_surface(gpu, oracle, tmp_path):
+    from spira_hip import raytracer as R
+    from spira_hip import scenes
+    # the bunny download is unavailable offline: write the procedural stand-in as an OBJ and load it like the test does
+    v, f = scenes.bumpy_blob(3)
+    path = tmp_path / "bunny.obj"
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for a, b, c in f:
+            fh.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+    world, camera = R.create_scene_with_obj(str(path))
+    img, hdr = R.render(world, camera, 64, 64, samples_per_pixel=1, max_depth=25, seed=2)     # render_example hard-codes depth 25 (:717)
+    assert img.shape == (64, 64, 3) and hdr.shape == (64, 64, 3)                                 # tests/bunny-test.jl:59
+    assert img.dtype == np.float32 and hdr.dtype == np.float64 and np.isfinite(hdr).all()
+    sp, ma, tr = R.flatten_world(world)
+    ohdr, oimg, _ = oracle.render(sp, ma, tr, camera.flat(), oracle.make_params(64, 64, 1, 25, len(sp), len(ma), len(tr), seed=2), "f64", want_img=True)
+    assert np.allclose(hdr, np.moveaxis(ohdr, 0, -1), rtol=1e-9, atol=1e-12)
+    assert np.allclose(R.to_acescg(hdr), img, atol=1e-6)
+    world2, camera2 = R.create_scene()
+    img2, hdr2 = R.render(world2, camera2, 80, 45, samples_per_pixel=4, max_depth=4, seed=3, precision="f32")
+    assert img2.shape == (45, 80, 3) and hdr2.dtype == np.float32
