@@ -27,8 +27,9 @@ def test_reference_script_call_shapes(gpu, oracle, tmp_path, w, h, spp, depth):
     out = str(tmp_path / "render.png")
     img = S.render(scene, cam, w, h, samples_per_pixel=spp, max_depth=depth, output_path=out, seed=1)
     assert img.shape == (h, w, 3) and img.dtype == np.float32 and img.min() >= 0 and img.max() <= 1
-    assert os.path.getsize(out) > 1000 and open(out, "rb").read(4) == b"\x89PNG"
-    assert img[0].mean() > img[-1].mean() * 0.5 and img[0, :, 2].mean() > 0.9      # row 0 is the sky (top), blue channel ~1
+    assert os.path.getsize(out) > 200 and open(out, "rb").read(4) == b"\x89PNG"
+    # row 0 is the sky (top): blue = sqrt(aces(1.0)) = 0.8965 after the K7 display transform
+    assert img[0].mean() > img[-1].mean() and abs(img[0, :, 2].mean() - 0.8965475) < 1e-5
     # the same call through the flat ABI arrays equals the oracle (semantics A + ACES/sqrt display transform)
     sd, md = S.prepare_scene_data(scene)
     ohdr, oimg, _ = oracle.render(sd.reshape(-1, 5), md.reshape(-1, 8), None, cam.flat(),
