@@ -166,6 +166,27 @@ int spira_render_device_f64(const double *spheres5, const double *materials8, co
                             const double camera12[12], const spira_params *params,
                             double *d_out_hdr, double *d_out_img, void *stream);
 
+/* ---- progressive accumulation (checkpoint / resume / adaptive sampling) ----
+ * The contract the reference's kernel was designed for and no host code uses: `current_sample_index`,
+ * persisted `rng_states`, `output_hdr_image[p] += L` (src/spira_path_trace_kernel.metal:143-145, :252-268).
+ * Renders samples [sample0, sample0 + params->spp) of every pixel of the tile and ADDS their radiance, in
+ * sample order, to sum_rgb (planar 3 x rows x width running sums, caller-owned; zero them before the first
+ * call).  image = sum_rgb / total samples; k calls of n samples leave bit for bit the sums of one call of k*n.
+ * rng_states (rows*width words, or NULL) is used by SPIRA_SEM_METAL only, whose LCG state runs from sample to
+ * sample: written by every call, read when sample0 > 0.  Host pointers, or device pointers + stream. */
+int spira_accumulate_f32(const float *spheres5, const float *materials8, const float *triangles10,
+                         const float camera12[12], const spira_params *params, uint32_t sample0,
+                         float *sum_rgb, uint32_t *rng_states);
+int spira_accumulate_f64(const double *spheres5, const double *materials8, const double *triangles10,
+                         const double camera12[12], const spira_params *params, uint32_t sample0,
+                         double *sum_rgb, uint32_t *rng_states);
+int spira_accumulate_device_f32(const float *spheres5, const float *materials8, const float *triangles10,
+                                const float camera12[12], const spira_params *params, uint32_t sample0,
+                                float *d_sum_rgb, uint32_t *d_rng_states, void *stream);
+int spira_accumulate_device_f64(const double *spheres5, const double *materials8, const double *triangles10,
+                                const double camera12[12], const spira_params *params, uint32_t sample0,
+                                double *d_sum_rgb, uint32_t *d_rng_states, void *stream);
+
 /* ---- diagnostics: per-segment trace of chosen paths (parity tests compare geometry bitwise) ----
  * ijs: n_paths x [i, j, sample] with i in 1..width, j in 1..height (the loop indices of
  * examples/julia-raytracer.jl:392-397) and sample in 0..spp-1.  Outputs, per path and bounce b <

@@ -180,6 +180,7 @@ template <class T> struct RenderConst {
     uint32_t row0, stripe_h, stripe_count, stripe_rank;
     uint32_t tile_pixels;        // rows * width
     uint32_t slots;              // k: sample slots per pass
+    uint32_t sample0;            // index of the first sample of this call (progressive accumulation; else 0)
 };
 
 // local output row -> reference loop row j (1-based, j = 1 is v = 0, the image bottom)
@@ -461,7 +462,7 @@ __device__ __forceinline__ void path_of(const RenderConst<T> &rc, uint32_t q, ui
     j = ref_row_j(rc, lr);
     i = lx + 1;
     pixel = (j - 1) * rc.width + lx;
-    sample = pass * rc.slots + slot;
+    sample = rc.sample0 + pass * rc.slots + slot;
 }
 
 // ------------------------------------------------------------------ ray queues (SoA of 16/32-byte packets)
@@ -957,7 +958,9 @@ __global__ __launch_bounds__(kBlock) void k_variant_cpu(const BounceArgs<T> a) {
 // SEM 2 = the .metal kernel's semantics: one lane per pixel walks all spp samples (its LCG state runs through
 // them, .metal :155/:268) and leaves their SUM in accum (the `output_hdr_image[p] += L` of :264).
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a, Pack4<T> *accum) {
+// Progressive use (`resume`): start from the sums already in accum and, when rng_states is given, from the LCG
+// states a previous call left there (the `rng_states[pixel_idx] = rng_state` of :268).
+__global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a, Pack4<T> *accum, uint32_t *rng_states, int resume) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
     const RenderConst<T> &rc = a.rc;
@@ -965,8 +968,9 @@ __global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a,
     for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < rc.tile_pixels; pl += gridDim.x * kBlock) {
         uint32_t pixel, sample, pi, pj;
         path_of<T>(rc, pl, 0, pi, pj, pixel, sample);
-        uint32_t st = metal_state0(rc.sA, rc.sB, pixel);
+        uint32_t st = ((resume & 2) && rng_states) ? rng_states[pl] : metal_state0(rc.sA, rc.sB, pixel);
         Vec<T> sum = mk<T>(0, 0, 0);
+        if (resume & 1) { const Pack4<T> l0 = accum[pl]; sum = mk<T>(l0.x, l0.y, l0.z); }
         for (uint32_t s = 0; s < rc.spp; ++s) {
             Vec<T> c;
             nseg += path_metal<T>(sc, rc, pi - 1, pj - 1, st, c, nullptr, nullptr, nullptr);
@@ -974,6 +978,7 @@ __global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a,
         }
         Pack4<T> l; l.x = sum.x; l.y = sum.y; l.z = sum.z; l.w = 0;
         accum[pl] = l;
+        if (rng_states) rng_states[pl] = st;
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
     if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
@@ -1052,6 +1057,15 @@ template <class T> __host__ __device__ inline T post1(T x, uint32_t post) {
     case 0x100u: return sqrt_any(aces1<T>(x));
     case 0x200u: { T v = x < 0 ? (T)0 : (x > 1 ? (T)1 : x); return sqrt_any(v); }
     default: return x;
+    }
+}
+
+// Progressive accumulation: load the caller's planar running sums into the accumulator.
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_load_accum(Pack4<T> *accum, const T *sum_planar, uint32_t tile_pixels) {
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < tile_pixels; p += gridDim.x * kBlock) {
+        Pack4<T> l; l.x = sum_planar[p]; l.y = sum_planar[tile_pixels + p]; l.z = sum_planar[2 * (size_t)tile_pixels + p]; l.w = 0;
+        accum[p] = l;
     }
 }
 

@@ -55,7 +55,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, scene, out_tmp, trace, bvh_nodes, bvh_tris;
+    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, scene, out_tmp, trace, bvh_nodes, bvh_tris, rng;
     uint64_t bvh_hash = 0; uint32_t bvh_n = 0; int bvh_prec = 0, bvh_depth = 0;   // cached tree (keyed by the triangle bytes)
     spira::Stats *h_stats = nullptr;          // pinned
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -166,6 +166,7 @@ void fill_const(spira::RenderConst<T> &rc, const T *cam, const spira_params *p, 
     else { rc.row0 = p->row0; rc.stripe_h = p->stripe_h; rc.stripe_count = p->stripe_count; rc.stripe_rank = p->stripe_rank; }
     rc.tile_pixels = rows * p->width;
     rc.slots = slots;
+    rc.sample0 = 0;
     rc.fd_tile = spira::fastdiv_make(rc.tile_pixels);
     rc.fd_width = spira::fastdiv_make(rc.width);
     rc.fd_stripe = spira::fastdiv_make(rc.stripe_h ? rc.stripe_h : 1);
@@ -252,10 +253,13 @@ int profile_events(Ctx &c, size_t need) {
 
 template <class T>
 int render_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
-                T *out_hdr, T *out_img, bool out_on_device, void *user_stream) {
+                T *out_hdr, T *out_img, bool out_on_device, void *user_stream,
+                bool progressive = false, uint32_t sample0 = 0, uint32_t *rng_states = nullptr) {
+    // progressive: out_hdr is the caller's running SUM (in/out), samples [sample0, sample0 + spp) are added to it
     uint32_t rows = 0;
     if (int rc = validate<T>(spheres5, materials8, triangles10, camera12, p, &rows)) return rc;
     if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
+    if (progressive && (uint64_t)sample0 + p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "sample0 + spp exceeds 2^24");
     Ctx *cp = nullptr;
     if (int rc = get_ctx(&cp)) return rc;
     Ctx &c = *cp;
@@ -338,13 +342,32 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     HIP_TRY(hipEventRecord(c.ev_start, st));
     uint64_t launches = 0;
 
+    // progressive accumulation: the caller's running sums (and, METAL, LCG states) seed the accumulator
+    a.rc.sample0 = progressive ? sample0 : 0;
+    uint32_t *d_rng = nullptr;
+    if (progressive) {
+        const uint32_t lblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
+        if (!out_on_device) HIP_TRY(hipMemcpyAsync(d_hdr, out_hdr, 3 * tile_pixels * sizeof(T), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((spira::k_load_accum<T>), dim3(lblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const T *)d_hdr, (uint32_t)tile_pixels);
+        ++launches;
+        if (rng_states) {
+            d_rng = rng_states;
+            if (!out_on_device) {
+                if (int rc = c.rng.ensure(tile_pixels * sizeof(uint32_t))) return rc;
+                d_rng = (uint32_t *)c.rng.p;
+                if (sample0 > 0) HIP_TRY(hipMemcpyAsync(d_rng, rng_states, tile_pixels * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            }
+        }
+    }
+
     if (p->max_depth == 0) {
-        HIP_TRY(hipMemsetAsync(c.accum.p, 0, tile_pixels * sizeof(P4), st));   // depth <= 0 -> Vec3(0,0,0), :330
+        if (!progressive) HIP_TRY(hipMemsetAsync(c.accum.p, 0, tile_pixels * sizeof(P4), st));   // depth <= 0 -> Vec3(0,0,0), :330
     } else if (sem == SPIRA_SEM_METAL) {
         // one launch: every lane owns a pixel and walks its spp samples (the LCG state runs through them)
         uint32_t blocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
         a.pass = 0; a.n_first = (uint32_t)tile_pixels;
-        hipLaunchKernelGGL((spira::k_variant_metal<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p);
+        hipLaunchKernelGGL((spira::k_variant_metal<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p, d_rng,
+                           progressive ? (sample0 > 0 ? 3 : 1) : 0);      // bit 0: continue the sums, bit 1: continue the LCG states
         ++launches;
     } else {
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
@@ -383,17 +406,23 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
             }
             uint32_t rblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
             hipLaunchKernelGGL((spira::k_resolve<T>), dim3(rblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const P4 *)c.L.p,
-                               (uint32_t)tile_pixels, k_eff, pass == 0 ? 1 : 0, mega ? (const uint32_t *)nullptr : (const uint32_t *)c.blkstats.p,
+                               (uint32_t)tile_pixels, k_eff, (pass == 0 && !progressive) ? 1 : 0, mega ? (const uint32_t *)nullptr : (const uint32_t *)c.blkstats.p,
                                p->max_depth, G * wpb, (spira::Stats *)c.stats.p);
             ++launches;
         }
     }
     {
         uint32_t fblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
-        hipLaunchKernelGGL((spira::k_finalize<T>), dim3(fblocks), dim3(spira::kBlock), 0, st, (const P4 *)c.accum.p, (uint32_t)tile_pixels,
-                           p->spp, p->flags & SPIRA_POST_MASK, d_hdr, d_img);
+        if (progressive)      // hand the running sums back untouched (x / 1 is exact)
+            hipLaunchKernelGGL((spira::k_finalize<T>), dim3(fblocks), dim3(spira::kBlock), 0, st, (const P4 *)c.accum.p, (uint32_t)tile_pixels,
+                               1u, (uint32_t)SPIRA_POST_NONE, d_hdr, (T *)nullptr);
+        else
+            hipLaunchKernelGGL((spira::k_finalize<T>), dim3(fblocks), dim3(spira::kBlock), 0, st, (const P4 *)c.accum.p, (uint32_t)tile_pixels,
+                               p->spp, p->flags & SPIRA_POST_MASK, d_hdr, d_img);
         ++launches;
     }
+    if (progressive && rng_states && !out_on_device)
+        HIP_TRY(hipMemcpyAsync(rng_states, d_rng, tile_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c.ev_stop, st));
     HIP_TRY(hipMemcpyAsync(c.h_stats, c.stats.p, sizeof(spira::Stats), hipMemcpyDeviceToHost, st));
@@ -551,7 +580,7 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); }
-        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.bvh_nodes.release(); c.bvh_tris.release(); c.bvh_hash = 0; c.bvh_n = 0;
+        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.bvh_nodes.release(); c.bvh_tris.release(); c.rng.release(); c.bvh_hash = 0; c.bvh_n = 0;
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
         (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop);
@@ -587,6 +616,27 @@ int spira_render_device_f32(const float *s, const float *m, const float *t, cons
 int spira_render_device_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, double *d_hdr,
                             double *d_img, void *stream) {
     return render_impl<double>(s, m, t, cam, p, d_hdr, d_img, true, stream);
+}
+
+int spira_accumulate_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t sample0,
+                         float *sum_rgb, uint32_t *rng_states) {
+    if (!sum_rgb) return fail(SPIRA_E_INVALID, "sum_rgb is NULL");
+    return render_impl<float>(s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
+}
+int spira_accumulate_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t sample0,
+                         double *sum_rgb, uint32_t *rng_states) {
+    if (!sum_rgb) return fail(SPIRA_E_INVALID, "sum_rgb is NULL");
+    return render_impl<double>(s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
+}
+int spira_accumulate_device_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t sample0,
+                                float *d_sum_rgb, uint32_t *d_rng_states, void *stream) {
+    if (!d_sum_rgb) return fail(SPIRA_E_INVALID, "d_sum_rgb is NULL");
+    return render_impl<float>(s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
+}
+int spira_accumulate_device_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t sample0,
+                                double *d_sum_rgb, uint32_t *d_rng_states, void *stream) {
+    if (!d_sum_rgb) return fail(SPIRA_E_INVALID, "d_sum_rgb is NULL");
+    return render_impl<double>(s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
 }
 
 int spira_trace_paths_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t n_paths,

@@ -25,7 +25,8 @@ EXPORTS = [
     "spira_abi_version", "spira_last_error", "spira_device_count", "spira_set_device", "spira_get_counters",
     "spira_shutdown", "spira_camera_lookat_f32", "spira_camera_lookat_f64", "spira_render_f32", "spira_render_f64",
     "spira_render_device_f32", "spira_render_device_f64", "spira_trace_paths_f32", "spira_trace_paths_f64",
-    "spira_tonemap_f32", "spira_stripe_rows",
+    "spira_tonemap_f32", "spira_stripe_rows", "spira_accumulate_f32", "spira_accumulate_f64", "spira_accumulate_device_f32",
+    "spira_accumulate_device_f64",
 ]
 
 
@@ -161,6 +162,23 @@ def render_device(spheres5, materials8, triangles10, camera12, params, d_hdr_ptr
     fn = lib().spira_render_device_f32 if prec == "f32" else lib().spira_render_device_f64
     _check(fn(sp, mp, tp, cp, C.byref(params), C.c_void_p(d_hdr_ptr or None), C.c_void_p(d_img_ptr or None),
               C.c_void_p(stream_ptr or None)))
+
+
+def accumulate(spheres5, materials8, triangles10, camera12, params, sample0, sum_rgb, rng_states=None, prec="f32"):
+    """Progressive accumulation: adds samples [sample0, sample0 + params.spp) to sum_rgb ([3, rows, W], in place)."""
+    npdt, _ = _dt(prec)
+    s, sp = _arr(spheres5, npdt)
+    m, mp = _arr(materials8, npdt)
+    t, tp = _arr(triangles10, npdt)
+    c, cp = _arr(camera12, npdt)
+    assert sum_rgb.dtype == npdt and sum_rgb.flags["C_CONTIGUOUS"]
+    rp = None
+    if rng_states is not None:
+        assert rng_states.dtype == np.uint32 and rng_states.flags["C_CONTIGUOUS"]
+        rp = rng_states.ctypes.data_as(C.c_void_p)
+    fn = lib().spira_accumulate_f32 if prec == "f32" else lib().spira_accumulate_f64
+    _check(fn(sp, mp, tp, cp, C.byref(params), C.c_uint32(sample0), sum_rgb.ctypes.data_as(C.c_void_p), rp))
+    return sum_rgb
 
 
 def trace_paths(spheres5, materials8, triangles10, camera12, params, ijs, prec="f32"):
