@@ -43,8 +43,10 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3", "s4"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "mega"])
-    ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--prec", default="f64", choices=["f32", "f64"],
+                    help="arithmetic type; f64 is the precision of the parity oracle examples/julia-raytracer.jl (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the informational run in the other precision")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="all ranks use GPU 0 and the gloo backend (not a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -114,27 +116,45 @@ def main():
     if rank == 0:
         assert bool(torch.isfinite(img).all()), "non-finite pixels"
         # ---- roofline leg: one extra render with every bounce launch bracketed by HIP events
-        roof = None
-        if args.kernel == "wavefront":
+        def roofline_leg(prec, out_t):
             pp = B.make_params(W, H, spp_total, depth, ns, nm, nt, flags=kflag | B.POST_NONE | B.FLAG_PROFILE,
                                seed=scenes.seed_for(3), **tile)
-            B.render_device(*sc, pp, out.data_ptr(), 0, stream.cuda_stream, args.prec)
+            B.render_device(*sc, pp, out_t.data_ptr(), 0, stream.cuda_stream, prec)
             torch.cuda.synchronize()
             c = B.counters()
-            nbytes = algorithmic_bytes(c, 4 if args.prec == "f32" else 8)
+            nbytes = algorithmic_bytes(c, 4 if prec == "f32" else 8)
             launches = max(1, c["bounce_launches"])
             avg_ms = c["bounce_kernel_ms"] / launches
             achieved = nbytes / (c["bounce_kernel_ms"] * 1e-3) / 1e9 if c["bounce_kernel_ms"] > 0 else 0.0
             traffic, tsrc = None, None
-            tfile = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.scene, args.prec))
+            tfile = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.scene, prec))
             if os.path.exists(tfile) and (W, H, spp_total, depth, world) == (1920, 1080, 64, 8, 1):
                 tj = json.load(open(tfile))      # PMC bytes per k_bounce launch of this same command (profiles/run_profile.sh)
                 traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(tfile)
-            roof = {"bound": "hbm", "kernel": "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            return {"bound": "hbm", "kernel": "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                     "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "bytes_per_sample": round(nbytes / c["samples"], 2), "segments_per_sample": round(c["segments"] / c["samples"], 4),
                     "bounce_kernel_share": round(c["bounce_kernel_ms"] / max(c["kernel_ms"], 1e-9), 4)}
+
+        roof = roofline_leg(args.prec, out) if args.kernel == "wavefront" else None
+        # ---- the same workload in the other precision (N=1 only; informational, never `value`)
+        alt = None
+        if world == 1 and not args.no_alt_precision:
+            ap_ = "f32" if args.prec == "f64" else "f64"
+            out2 = torch.empty((3, rows, W), dtype=torch.float32 if ap_ == "f32" else torch.float64, device="cuda")
+            B.render_device(*sc, params, out2.data_ptr(), 0, stream.cuda_stream, ap_)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                B.render_device(*sc, params, out2.data_ptr(), 0, stream.cuda_stream, ap_)
+            torch.cuda.synchronize()
+            adt = (time.perf_counter() - t1) / 3
+            aroof = roofline_leg(ap_, out2) if args.kernel == "wavefront" else None
+            alt = {"dtype": ap_, "value": round(samples_per_step / adt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(adt * 1e3, 3),
+                   "roofline_frac": aroof and aroof["frac"], "achieved_GBps": aroof and aroof["achieved"],
+                   "bytes_per_sample": aroof and aroof["bytes_per_sample"]}
+            del out2
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -165,7 +185,7 @@ def main():
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": args.scene, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "other_precision": alt,
         }
         print(json.dumps(result), flush=True)
     if world > 1:

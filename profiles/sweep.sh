@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
 for cfg in "$@"; do
   for sc in ${SCENES:-s1 s3}; do
-    line=$(env $cfg timeout -k 10 120 python3 bench.py --steps ${STEPS:-3} --no-cpu-baseline --scene $sc ${BENCH_ARGS:-} 2>&1 | tail -1)
+    line=$(env $cfg timeout -k 10 120 python3 bench.py --steps ${STEPS:-3} --no-cpu-baseline --no-alt-precision --scene $sc ${BENCH_ARGS:-} 2>&1 | tail -1)
     echo "$cfg $sc -> $(echo "$line" | python3 -c 'import sys,json
 try:
     d=json.loads(sys.stdin.read()); r=d.get("roofline") or {}
