@@ -31,6 +31,12 @@
  *       replaces  to_acescg examples/julia-raytracer.jl:370-384, gpu_tone_map_kernel!
  *                 src/spira-metal-optimized.jl:1128-1144 and the clamp+sqrt of
  *                 render_with_cpu :1441-1442.
+ *   spira_accumulate_f32/_f64 (+ _device_)
+ *       the progressive contract of src/spira_path_trace_kernel.metal:143-145,:252-268
+ *       (current_sample_index, persisted rng_states, output += L), which no reference host code drives.
+ *   flags & SPIRA_SEM_MASK selects which of the reference's estimators runs:
+ *       ray_color (examples/julia-raytracer.jl:328-367, default), trace_ray of render_with_cpu
+ *       (src/spira-metal-optimized.jl:1351-1412), path_trace (src/spira_path_trace_kernel.metal:140-269).
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a
  * negative SPIRA_E_* code otherwise; nothing throws, aborts or calls back across the ABI;

@@ -13,7 +13,6 @@ namespace spira {
 
 constexpr int kBlock = 256;          // 4 waves of 64
 constexpr uint32_t kMaxTries = 64;   // bounded rejection sampling (P(exhaust) ~ 2e-21)
-constexpr size_t kCompactScratchBytes = 0;    // (k_bounce keeps one work list per wave behind the LDS scene)
 
 // ------------------------------------------------------------------ small vector algebra
 // Operation order mirrors Vec3 of examples/julia-raytracer.jl:11-41.

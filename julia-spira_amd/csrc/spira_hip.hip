@@ -3,9 +3,9 @@
 //
 // Replaces the host loops of render_hybrid_gpu (src/spira-metal-optimized.jl:1228-1343): the
 // reference launches >= spp*(1 + max_depth*(12*n_spheres + 4)) synchronous kernels with host
-// round trips per depth; here one pass = 1 memset + max_depth bounce kernels
-// + 1 resolve kernel, fully asynchronous on one HIP stream, the live-ray count staying on the
-// device (counts[]), and a pass carries `slots` samples of every pixel of the tile at once.
+// round trips per depth; here one pass = max_depth bounce kernels + 1 resolve
+// kernel, fully asynchronous on one HIP stream, the live-ray counts staying on the device (one
+// word per wave), and a pass carries `slots` samples of every pixel of the tile at once.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -320,7 +320,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     a.L = (P4 *)c.L.p;
     a.stats = (spira::Stats *)c.stats.p;
 
-    const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + spira::kCompactScratchBytes;
+    const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles);
     const uint32_t n_pass = (p->spp + slots - 1) / slots;
 
     T *d_hdr = out_hdr, *d_img = out_img;
@@ -478,7 +478,7 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     T *d_ra = (T *)(base + b_ij + b_pr + b_ts + b_di);
     HIP_TRY(hipMemcpyAsync(d_ij, ijs, (size_t)n_paths * 3 * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_ts, 0, b_ts + b_di, st));
-    const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + spira::kCompactScratchBytes;
+    const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles);
     const uint32_t sem = p->flags & SPIRA_SEM_MASK;
     if (sem == SPIRA_SEM_CPU) hipLaunchKernelGGL((spira::k_trace_variant<T, 1>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
     else if (sem == SPIRA_SEM_METAL) hipLaunchKernelGGL((spira::k_trace_variant<T, 2>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
