@@ -12,7 +12,7 @@ module SPIRA
 using StaticArrays
 
 export Scene, Camera, Ray, Sphere, Material, Point3, Vec3, Color,
-       render_hybrid_gpu, render, create_scene, prepare_scene_data
+       render_hybrid_gpu, render_with_cpu, render, create_scene, prepare_scene_data
 
 const libspira = get(ENV, "SPIRA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libspira_hip.so"))
 
@@ -118,6 +118,12 @@ function render_hybrid_gpu(width::Int, height::Int, scene::Scene, camera::Camera
     rc == 0 || spira_error(rc)
     return permutedims(planar, (2, 1, 3))                   # (H, W, 3), row 1 = top
 end
+
+# render_with_cpu(width, height, scene, camera; ...) (:1346-1450, exported by src/SPIRA.jl:13): same estimator
+# (trace_ray :1351-1412 = SPIRA_SEM_CPU) and display transform (clamp + sqrt :1441-1442), executed by the HIP kernels.
+render_with_cpu(width::Int, height::Int, scene::Scene, camera::Camera; samples_per_pixel::Int=16, max_depth::Int=4, seed::Integer=0) =
+    render_hybrid_gpu(width, height, scene, camera; samples_per_pixel=samples_per_pixel, max_depth=max_depth, seed=seed,
+                      flags=0x00000001 | 0x00000200)        # SPIRA_SEM_CPU | SPIRA_POST_CLAMP_GAMMA
 
 # render(scene, camera, width, height; samples_per_pixel=16, max_depth=4, output_path=...)  (:1453-1490)
 function render(scene::Scene, camera::Camera, width::Int, height::Int;

@@ -6,7 +6,7 @@ examples/basic_render.jl:22-25 use but the reference forgets to export).
 from . import _binding, raytracer, scenes  # noqa: F401
 from ._binding import SpiraError, build_library  # noqa: F401
 from .spira import (BLACK, WHITE, Camera, Color, Material, Point3, Ray, Scene, Sphere, Vec3, create_scene,  # noqa: F401
-                    prepare_scene_data, render, render_hybrid_gpu)
+                    prepare_scene_data, render, render_hybrid_gpu, render_with_cpu)
 
-__all__ = ["Scene", "Camera", "Ray", "Sphere", "Material", "Point3", "Vec3", "Color", "render_hybrid_gpu", "render",
-           "create_scene", "prepare_scene_data", "SpiraError"]
+__all__ = ["Scene", "Camera", "Ray", "Sphere", "Material", "Point3", "Vec3", "Color", "render_hybrid_gpu", "render_with_cpu",
+           "render", "create_scene", "prepare_scene_data", "SpiraError"]

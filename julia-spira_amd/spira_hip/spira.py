@@ -4,7 +4,7 @@ Same names, argument meaning and defaults as the reference's Julia API, implemen
 C ABI of libspira_hip.so (the executable twin of julia-spira_amd/julia/SPIRA.jl, whose `ccall`s
 bind the same symbols).  `render` dispatches to the HIP backend where the reference's
 `render` (:1453-1490) picks Metal/CUDA; there is no CPU fallback here — `render_with_cpu`
-(:1346-1450) is intentionally not provided by the product.
+(:1346-1450) keeps its name and estimator but runs on the GPU too.
 """
 import time
 
@@ -139,6 +139,14 @@ def render_hybrid_gpu(width, height, scene, camera, samples_per_pixel=16, max_de
                       flags=sem | kernel | (default_post if post is None else post), seed=seed)
     _, img = B.render(sphere_data, material_data, None, camera.flat(), p, prec="f32", want_hdr=False, want_img=True)
     return np.ascontiguousarray(np.moveaxis(img, 0, -1))
+
+
+def render_with_cpu(width, height, scene, camera, samples_per_pixel=16, max_depth=4, seed=0):
+    """render_with_cpu(width, height, scene, camera; samples_per_pixel, max_depth) (:1346-1450), exported by
+    src/SPIRA.jl:13.  Same estimator (`trace_ray`, :1351-1412) and the same clamp + sqrt display transform
+    (:1441-1442) — executed by the HIP kernels, not on the CPU: there is no CPU renderer in this package."""
+    return render_hybrid_gpu(width, height, scene, camera, samples_per_pixel=samples_per_pixel, max_depth=max_depth, seed=seed,
+                             semantics="cpu")
 
 
 def render(scene, camera, width, height, samples_per_pixel=16, max_depth=4, output_path="metal_optimized_render.png",

@@ -109,7 +109,7 @@ def test_no_gpu_means_loud_failure(binding):
 def test_mirror_api_surface(binding):
     import spira_hip
     from spira_hip import raytracer
-    for name in ["Scene", "Camera", "Ray", "Sphere", "Material", "render_hybrid_gpu", "render", "create_scene",
+    for name in ["Scene", "Camera", "Ray", "Sphere", "Material", "render_hybrid_gpu", "render_with_cpu", "render", "create_scene",
                  "Point3", "Vec3", "Color"]:   # src/SPIRA.jl:11-13 + README.md:50-53
         assert hasattr(spira_hip, name)
     scene = spira_hip.create_scene()
