@@ -1,13 +1,14 @@
 """Multi-GPU sharding of the path: one process per GPU, image rows dealt to the
-ranks as interleaved stripes, NO data-path collective while rendering, one gather of the tiles
+ranks as interleaved stripes, NO data-path collective while rendering, one all-gather of the tiles
 at the end (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
 
-The RNG is keyed by the global pixel, so the assembled image is bit-identical for any
-world size / stripe height (tests/test_distributed_cpu.py, tests/test_gpu_parity.py).
+The RNG is keyed by the global pixel, so the assembled image is bit-identical for any world
+size / stripe height (tests/test_distributed_cpu.py, tests/test_gpu_parity.py).
 """
 import numpy as np
 
 DEFAULT_STRIPE_H = 8
+_plans = {}
 
 
 def rows_of_rank(height, world, rank, stripe_h=DEFAULT_STRIPE_H):
@@ -32,6 +33,16 @@ def max_rows(height, world, stripe_h=DEFAULT_STRIPE_H):
     return max(len(rows_of_rank(height, world, r, stripe_h)) for r in range(world))
 
 
+def source_of_rows(height, world, stripe_h=DEFAULT_STRIPE_H):
+    """For every global row y: (rank that rendered it, its local row there)."""
+    src_rank = np.zeros(height, dtype=np.int64)
+    src_row = np.zeros(height, dtype=np.int64)
+    for r in range(world):
+        for lr, y in enumerate(rows_of_rank(height, world, r, stripe_h)):
+            src_rank[y], src_row[y] = r, lr
+    return src_rank, src_row
+
+
 def assemble(tiles, height, world, stripe_h=DEFAULT_STRIPE_H):
     """tiles[r]: array-like [3, >= rows_r, W] (numpy or torch) -> full image [3, height, W]."""
     first = tiles[0]
@@ -50,26 +61,43 @@ def assemble(tiles, height, world, stripe_h=DEFAULT_STRIPE_H):
 
 
 def gather_image(local_tile, height, stripe_h=DEFAULT_STRIPE_H, dst=0):
-    """Gather every rank's tile (torch tensor [3, rows_r, W]) to `dst` and assemble [3, height, W].
+    """All-gather every rank's tile (torch tensor [3, rows_r, W]) and assemble [3, height, W] on `dst`.
 
-    One collective: tiles are padded to the largest tile so a single all_gather moves
-    3*rows*W values per rank (3.1 MB per GPU at 1080p / 8 GPUs).  Returns None off `dst`.
+    One collective per frame: tiles are padded to the largest tile and land in one [world, 3, rows, W]
+    buffer (ncclAllGather; 3.1 MB per GPU at 1080p / 8 GPUs); the row permutation back to image order is one
+    indexed copy with index tensors built once per geometry.  Returns None off `dst`.
     """
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return local_tile
-    mr = max_rows(height, world, stripe_h)
-    if local_tile.shape[1] != mr:
-        padded = local_tile.new_zeros((3, mr, local_tile.shape[2]))
-        padded[:, :local_tile.shape[1]] = local_tile
-    else:
+    W = local_tile.shape[2]
+    key = (height, world, stripe_h, W, local_tile.dtype, str(local_tile.device))
+    plan = _plans.get(key)
+    if plan is None:
+        mr = max_rows(height, world, stripe_h)
+        sr, sl = source_of_rows(height, world, stripe_h)
+        plan = dict(mr=mr, stacked=local_tile.new_empty((world, 3, mr, W)), padded=local_tile.new_zeros((3, mr, W)),
+                    src_rank=torch.as_tensor(sr, device=local_tile.device), src_row=torch.as_tensor(sl, device=local_tile.device))
+        _plans[key] = plan
+    if local_tile.shape[1] == plan["mr"]:
         padded = local_tile.contiguous()
-    # all_gather is the collective every backend implements natively (RCCL: one ncclAllGather); the extra
-    # copies on the non-destination ranks are 25 MB at 1080p and keep the code to one well-trodden call
-    bufs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(bufs, padded)
+    else:
+        padded = plan["padded"]
+        padded[:, :local_tile.shape[1]] = local_tile
+    # gather: only `dst` needs the tiles, and on xGMI the world-1 point-to-point transfers arrive over separate
+    # links at once (an all-gather would also ship every tile to every other rank: 7x the traffic on a ring)
+    if plan.get("mode", "gather") == "gather":
+        try:
+            dist.gather(padded, list(plan["stacked"].unbind(0)) if rank == dst else None, dst=dst)
+        except (RuntimeError, NotImplementedError, ValueError):    # a backend without gather: all-gather is universal
+            plan["mode"] = "all_gather"
+    if plan.get("mode") == "all_gather":
+        try:
+            dist.all_gather_into_tensor(plan["stacked"], padded)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(plan["stacked"].unbind(0)), padded)
     if rank != dst:
         return None
-    return assemble(bufs, height, world, stripe_h)
+    return plan["stacked"][plan["src_rank"], :, plan["src_row"]].permute(1, 0, 2).contiguous()
