@@ -27,9 +27,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 
 def algorithmic_bytes(c, prec_bytes):
     """HBM bytes the wavefront formulation must move (DESIGN.md "Roofline"), from device counters:
-    every enqueued ray is written once and read once (10 values), a radiance term is a 4-value store, or a
-    read-modify-write (2 x 4 values) when the path already holds radiance."""
-    return (2 * 10 * c["rays_enqueued"] + 4 * c["radiance_stores"] + 8 * c["radiance_rmw"]) * prec_bytes
+    every enqueued ray is written once and read once (10 values), a radiance term is a 3-value store, or a
+    read-modify-write (2 x 3 values) when the path already holds radiance."""
+    return (2 * 10 * c["rays_enqueued"] + 3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes
 
 
 def main():

@@ -37,6 +37,7 @@ template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a) { retur
 // ------------------------------------------------------------------ 16/32-byte packets
 template <class T> struct alignas(4 * sizeof(T)) Pack4 { T x, y, z, w; };
 template <class T> struct alignas(2 * sizeof(T)) Pack2 { T x, y; };
+template <class T> struct alignas(sizeof(T)) Pack3 { T x, y, z; };      // radiance triples: no padding moved through HBM
 
 template <class T> struct Bits;
 template <> struct Bits<float> {
@@ -495,7 +496,7 @@ template <class T> struct BounceArgs {
     SceneGlobal<T> scene;
     RenderConst<T> rc;
     RayQueue<T> qin, qout;
-    Pack4<T> *L;                     // per-path radiance of the pass batch (slot-major), 16/32 B each
+    Pack3<T> *L;                     // per-path radiance of the pass batch (slot-major), 12 / 24 B each
     const uint32_t *cnt_in;          // [NW] rays waiting in each wave's region of qin (bounce >= 1)
     uint32_t *cnt_out;               // [NW] survivors this bounce leaves in each region of qout
     uint32_t *blk_stats;             // [NW][4] segments traced, radiance RMWs, radiance stores of this launch
@@ -615,13 +616,13 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
                 const uint32_t qi = q[r] & 0x7FFFFFFFu;
                 const bool has_l = (q[r] >> 31) != 0;
                 if (si.has_contrib) {
-                    Pack4<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z; l.w = 0;
-                    if (has_l) { const Pack4<T> l0 = a.L[qi]; l.x = l0.x + contrib.x; l.y = l0.y + contrib.y; l.z = l0.z + contrib.z; ++n_rmw; }
+                    Pack3<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z;
+                    if (has_l) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + contrib.x; l.y = l0.y + contrib.y; l.z = l0.z + contrib.z; ++n_rmw; }
                     else ++n_store;
                     a.L[qi] = l;
                     q[r] |= 0x80000000u;
                 } else if (!si.alive && !has_l) {              // path ends without ever having contributed
-                    Pack4<T> l; l.x = 0; l.y = 0; l.z = 0; l.w = 0;
+                    Pack3<T> l; l.x = 0; l.y = 0; l.z = 0;
                     a.L[qi] = l;
                     ++n_store;
                 }
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(const BounceArgs<T> a) {
             else if (si.has_contrib) Lacc = Lacc + contrib;
             if (!si.alive) break;
         }
-        Pack4<T> l; l.x = Lacc.x; l.y = Lacc.y; l.z = Lacc.z; l.w = 0;
+        Pack3<T> l; l.x = Lacc.x; l.y = Lacc.y; l.z = Lacc.z;
         a.L[idx] = l;
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(kBlock) void k_variant_cpu(const BounceArgs<T> a) {
         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
         Vec<T> Lp;
         nseg += path_cpu<T>(sc, rc, pi, pj, sample, Lp, nullptr, nullptr, nullptr);
-        Pack4<T> l; l.x = Lp.x; l.y = Lp.y; l.z = Lp.z; l.w = 0;
+        Pack3<T> l; l.x = Lp.x; l.y = Lp.y; l.z = Lp.z;
         a.L[idx] = l;
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
@@ -1030,23 +1031,23 @@ __global__ __launch_bounds__(64) void k_trace_variant(const BounceArgs<T> a, con
 // `color = color + ray_color(...)` of examples/julia-raytracer.jl:401 in the same order.
 // Workgroup 0 also folds the pass's per-workgroup statistics [n_bounce][G][2] into the render totals.
 template <class T>
-__global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack4<T> *L, uint32_t tile_pixels, uint32_t k_eff, int first_pass,
+__global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack3<T> *L, uint32_t tile_pixels, uint32_t k_eff, int first_pass,
                                                     const uint32_t *blk_stats, uint32_t n_bounce, uint32_t G, Stats *stats) {
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < tile_pixels; p += gridDim.x * kBlock) {
         Pack4<T> acc;
         if (first_pass) { acc.x = 0; acc.y = 0; acc.z = 0; acc.w = 0; } else acc = accum[p];
-        // eight independent 16/32-byte loads in flight per lane, then the adds in sample order (the sum order is
-        // the reference's; only the loads are batched — a load/add/load/add loop ran at 2.6 TB/s)
+        // eight independent 12/24-byte loads in flight per lane, then the adds in sample order (the sum order is
+        // the reference's; only the loads are batched)
         uint32_t s = 0;
         for (; s + 8 <= k_eff; s += 8) {
-            Pack4<T> l[8];
+            Pack3<T> l[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) l[k] = L[(size_t)(s + k) * tile_pixels + p];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { acc.x = acc.x + l[k].x; acc.y = acc.y + l[k].y; acc.z = acc.z + l[k].z; }
         }
         for (; s < k_eff; ++s) {
-            const Pack4<T> l = L[(size_t)s * tile_pixels + p];
+            const Pack3<T> l = L[(size_t)s * tile_pixels + p];
             acc.x = acc.x + l.x; acc.y = acc.y + l.y; acc.z = acc.z + l.z;
         }
         accum[p] = acc;

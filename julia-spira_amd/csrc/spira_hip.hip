@@ -268,7 +268,8 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
 
     const uint32_t W = p->width;
     const uint64_t tile_pixels = (uint64_t)rows * W;
-    uint32_t target = p->batch_rays ? p->batch_rays : env_u32("SPIRA_BATCH_RAYS", 64u << 20);
+    // default pass size: 160 Mi rays (a 1080p x 64 spp frame is one pass); ~16 GB (f32) / 31 GB (f64) of the 288 GB
+    uint32_t target = p->batch_rays ? p->batch_rays : env_u32("SPIRA_BATCH_RAYS", 160u << 20);
     uint64_t slots64 = std::max<uint64_t>(1, target / tile_pixels);
     slots64 = std::min<uint64_t>(slots64, p->spp);
     if (slots64 * tile_pixels > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "tile too large: rows*width must be < 2^31");
@@ -305,7 +306,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
             if (int rc = c.qB[i].ensure(q_rays * sizeof(P4))) return rc;
             if (int rc = c.qC[i].ensure(q_rays * sizeof(P2))) return rc;
         }
-    if (int rc = c.L.ensure(batch * sizeof(P4))) return rc;
+    if (int rc = c.L.ensure(batch * sizeof(spira::Pack3<T>))) return rc;
     if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
     if (int rc = c.counts.ensure((size_t)(SPIRA_MAX_DEPTH + 2) * G_max * wpb * sizeof(uint32_t))) return rc;
     if (int rc = c.blkstats.ensure((size_t)(SPIRA_MAX_DEPTH + 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
@@ -317,7 +318,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     if (!fastdiv_selfcheck(a.rc.tile_pixels, (uint32_t)batch) || !fastdiv_selfcheck(a.rc.width, a.rc.tile_pixels) ||
         !fastdiv_selfcheck(a.rc.stripe_h ? a.rc.stripe_h : 1, rows))
         return fail(SPIRA_E_LIMIT, "internal: fast division self-check failed");
-    a.L = (P4 *)c.L.p;
+    a.L = (spira::Pack3<T> *)c.L.p;
     a.stats = (spira::Stats *)c.stats.p;
 
     const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles);
@@ -405,7 +406,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
                 }
             }
             uint32_t rblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
-            hipLaunchKernelGGL((spira::k_resolve<T>), dim3(rblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const P4 *)c.L.p,
+            hipLaunchKernelGGL((spira::k_resolve<T>), dim3(rblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const spira::Pack3<T> *)c.L.p,
                                (uint32_t)tile_pixels, k_eff, (pass == 0 && !progressive) ? 1 : 0, mega ? (const uint32_t *)nullptr : (const uint32_t *)c.blkstats.p,
                                p->max_depth, G * wpb, (spira::Stats *)c.stats.p);
             ++launches;
