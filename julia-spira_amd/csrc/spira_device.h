@@ -12,6 +12,16 @@
 namespace spira {
 
 constexpr int kBlock = 256;          // 4 waves of 64
+// k_bounce register budget (second __launch_bounds__ argument = minimum waves per SIMD), from a same-device A/B
+// of builds (S1 / S3 Msamples/s): f32 4: 22 766 / 4 296, 5: 22 795 / 4 308, 6: 17 844 / 3 601, 8: 9 037 / 2 050;
+// f64 3: 15 368 / 2 876, 4: 15 723 / 2 964, 5: 11 425 / 2 339.  (f64 without a bound takes 132 VGPRs -> 3 waves.)
+#ifndef SPIRA_WAVES_F32
+#define SPIRA_WAVES_F32 5
+#endif
+#ifndef SPIRA_WAVES_F64
+#define SPIRA_WAVES_F64 4
+#endif
+#define SPIRA_WAVES_PER_SIMD(T) (sizeof(T) == 8 ? SPIRA_WAVES_F64 : SPIRA_WAVES_F32)
 constexpr uint32_t kMaxTries = 64;   // bounded rejection sampling (P(exhaust) ~ 2e-21)
 
 // ------------------------------------------------------------------ small vector algebra
@@ -539,7 +549,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 //      the wave's region; survivors land in consecutive slots, so the 16-byte packet stores coalesce.
 // Results do not depend on which lane produced a random vector: it is a pure function of its key.
 template <class T, bool FIRST, int R, bool BVH>
-__global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
+__global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(const BounceArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -573,15 +583,6 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
         uint32_t q[R], ent[R];
         uint32_t n_list = 0;
         // ---------------- phase 1
-        Pack4<T> inA[R], inB[R];
-        Pack2<T> inC[R];
-        if (!FIRST) {                  // all R rays' packet loads in flight before the first one is used
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t idx = sub * SUB + r * 64 + lane;
-                if (idx < limit) { inA[r] = a.qin.A[region + idx]; inB[r] = a.qin.B[region + idx]; inC[r] = a.qin.C[region + idx]; }
-            }
-        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t idx = sub * SUB + r * 64 + lane;
@@ -597,8 +598,8 @@ __global__ __launch_bounds__(kBlock) void k_bounce(const BounceArgs<T> a) {
                     camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
                     beta[r] = mk<T>(1, 1, 1);
                 } else {
-                    const Pack4<T> A = inA[r], B = inB[r];
-                    const Pack2<T> C = inC[r];
+                    const Pack4<T> A = a.qin.A[region + idx], B = a.qin.B[region + idx];
+                    const Pack2<T> C = a.qin.C[region + idx];
                     o[r] = mk<T>(A.x, A.y, A.z);
                     d = mk<T>(A.w, B.x, B.y);
                     beta[r] = mk<T>(B.z, B.w, C.x);

@@ -231,7 +231,6 @@ int upload_scene(Ctx &c, hipStream_t st, const T *spheres5, const T *materials8,
 template <class T, bool FIRST, bool BVH>
 void launch_bounce_r(int R, dim3 grid, size_t lds, hipStream_t st, const spira::BounceArgs<T> &a) {
     switch (R) {
-    case 4: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 4, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
     case 2: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 2, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
     default: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 1, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
     }
@@ -280,7 +279,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA || sem != SPIRA_SEM_A;
     const bool profile = (p->flags & SPIRA_FLAG_PROFILE) != 0 && !mega;
     int R = (int)env_u32("SPIRA_R", 2);
-    if (R != 1 && R != 2 && R != 4) R = 2;
+    if (R != 1 && R != 2) R = 2;
 
     // ---- launch geometry: NW = 4*G autonomous waves per bounce kernel, each owning `cap` rays of both queues
     const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", 16);

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC, "libspira_hip.so")
+LIB_PATH = os.environ.get("SPIRA_HIP_LIB", os.path.join(CSRC, "libspira_hip.so"))   # same override as julia/SPIRA.jl
 
 # ---- flags (include/spira_hip.h) ----
 SEM_A, SEM_CPU, SEM_METAL = 0x0, 0x1, 0x2
