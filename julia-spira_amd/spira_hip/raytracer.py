@@ -184,3 +184,16 @@ def render(world, camera, width, height, samples_per_pixel=50, max_depth=20, see
                       0 if triangles10 is None else len(triangles10), flags=B.SEM_A | kernel | B.POST_ACES, seed=seed)
     hdr, img = B.render(spheres5, materials8, triangles10, camera.flat(), p, prec=precision, want_hdr=True, want_img=True)
     return (np.ascontiguousarray(np.moveaxis(img, 0, -1)).astype(np.float32), np.ascontiguousarray(np.moveaxis(hdr, 0, -1)))
+
+
+def save_exr(hdr_data, filename):
+    """save_exr(hdr_data, filename) (:424-463): 32-bit float EXR of the linear radiance; on failure the
+    to_acescg PNG next to it and False, like the reference's fallback branch."""
+    from . import exr, png
+    try:
+        exr.save_exr(filename, hdr_data)
+        return True
+    except (OSError, ValueError) as e:
+        print("Error saving EXR file: %s\nSaving as PNG instead..." % (e,))
+        png.save_png(filename.replace(".exr", ".png"), to_acescg(hdr_data))
+        return False
