@@ -169,9 +169,15 @@ def main():
             t1 = time.perf_counter()
             O.render(*sc, O.make_params(W, H, cpu_spp, depth, ns, nm, nt, seed=scenes.seed_for(3)), "f64", n_threads=cores)
             cdt = time.perf_counter() - t1
+            # the reference's own loop is serial (examples/julia-raytracer.jl:392): one thread, the middle 64 rows at spp 16
+            t1 = time.perf_counter()
+            O.render(*sc, O.make_params(W, H, 16, depth, ns, nm, nt, seed=scenes.seed_for(3), row0=H // 2 - 32, rows=64), "f64", n_threads=1)
+            sdt = time.perf_counter() - t1
             cpu = {"value": round(W * H * cpu_spp / cdt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
                    "sample": "%dx%d spp=%d depth=%d, same scene/seed, Float64 oracle (oracle/spira_oracle.c, OpenMP over rows), %.1f s"
-                             % (W, H, cpu_spp, depth, cdt)}
+                             % (W, H, cpu_spp, depth, cdt),
+                   "single_thread_value": round(W * 64 * 16 / sdt / 1e6, 4),
+                   "single_thread_sample": "rows %d..%d of the same frame at spp=16, 1 thread, %.1f s" % (H // 2 - 32, H // 2 + 31, sdt)}
         result = {
             "metric": "Msamples/sec at 1920x1080 spp=64 depth=8; fraction of HBM roofline",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
