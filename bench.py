@@ -32,6 +32,21 @@ def algorithmic_bytes(c, prec_bytes):
     return (2 * 10 * c["rays_enqueued"] + 3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: affinity mask capped by the cgroup quota (cpu.max / cfs_quota_us)."""
+    n = len(os.sched_getaffinity(0))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +111,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:       # connection setup only (no rendering): RCCL opens its point-to-point channels at the first gather
+        out.zero_()
+        D.gather_image(out, H)
     for _ in range(args.warmup):
         step()
     fence()
@@ -159,7 +177,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle_py as O
-            cores = O.max_threads()
+            cores = min(O.max_threads(), host_cpu_share())     # the box's cgroup CPU share, not the host's core count
             O.render(*sc, O.make_params(W, H, 1, depth, ns, nm, nt, seed=scenes.seed_for(3), rows=8), "f64", n_threads=cores)   # spin up the threads
             t1 = time.perf_counter()
             O.render(*sc, O.make_params(W, H, 2, depth, ns, nm, nt, seed=scenes.seed_for(3)), "f64", n_threads=cores)
