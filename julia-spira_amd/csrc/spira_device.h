@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "spira_sqrt.h"
 
 namespace spira {
 
@@ -38,8 +39,6 @@ template <class T> __device__ __forceinline__ T dot(Vec<T> a, Vec<T> b) { return
 template <class T> __device__ __forceinline__ Vec<T> cross(Vec<T> a, Vec<T> b) {
     return mk<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }   // correctly rounded (hipcc default)
-__device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
 __device__ __forceinline__ float abs_t(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double abs_t(double x) { return __builtin_fabs(x); }
 template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a) { return a / sqrt_rn(dot(a, a)); }  // :27-28
