@@ -42,3 +42,35 @@ def test_small_batches_many_passes(gpu):
     ref, _ = gpu.render(*_args(s), gpu.make_params(64, 36, 33, 5, ns, nm, seed=2), "f32")
     got, _ = gpu.render(*_args(s), gpu.make_params(64, 36, 33, 5, ns, nm, seed=2, batch_rays=1), "f32")   # 33 passes of one slot
     assert np.array_equal(ref, got) and gpu.counters()["passes"] == 33
+
+
+def test_config4_full_size_shard_equals_frame_rows(gpu):
+    """BASELINE configs[3] (1920x1080, spp 256, depth 8, 8 GPUs): what rank 3 of 8 renders (its interleaved 8-row stripes) is,
+    bit for bit, those rows of the whole frame rendered on one device; the shard's sample count is 1/8 of the frame's."""
+    from spira_hip import distributed as D
+    s = scenes.scene_s3()
+    ns, nm, nt = _counts(s)
+    W, H, spp, depth = 1920, 1080, 256, 8
+    full, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(4)), "f32")
+    tile = D.tile_params(H, 8, 3)
+    part, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(4), **tile), "f32")
+    c = gpu.counters()
+    rows = D.rows_of_rank(H, 8, 3)
+    assert part.shape == (3, len(rows), W) and np.array_equal(part, full[:, rows])
+    # closed box: paths run to max_depth, except the ~1e-6 that slip through a wall seam inside t_min (DESIGN.md, S3)
+    assert c["samples"] == len(rows) * W * spp and c["samples"] * depth * (1 - 1e-4) < c["segments"] <= c["samples"] * depth
+
+
+def test_config5_full_size_mesh_properties(gpu):
+    """BASELINE configs[4] shape (1920x1080, depth 12, ~82 k triangles through the BVH) at spp 4: wavefront == megakernel bit for bit,
+    a row slab equals the frame's rows, every pixel finite and non-negative."""
+    s = scenes.scene_s4()
+    ns, nm, nt = _counts(s)
+    W, H, spp, depth = 1920, 1080, 4, 12
+    wf, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(5)), "f32")
+    seg = gpu.counters()["segments"]
+    mg, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(5), flags=gpu.KERNEL_MEGA), "f32")
+    assert np.array_equal(wf, mg) and gpu.counters()["segments"] == seg
+    slab, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(5), row0=400, rows=96), "f32")
+    assert np.array_equal(slab, wf[:, 400:496])
+    assert np.isfinite(wf).all() and wf.min() >= 0 and nt > 80000 and W * H * spp < seg <= W * H * spp * depth
