@@ -1,6 +1,8 @@
 """GPU (MI355X): seeded fuzz of the C ABI against the oracle — random image sizes, spp, depth, tilings, batch sizes,
 kernel organisations, precisions, estimators and scenes (spheres, LDS triangles, BVH meshes).  Every case: image within
 the north-star tolerance of the oracle and identical segment counts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -31,8 +33,9 @@ def _case(rng):
 
 
 def test_fuzz_against_oracle(gpu, oracle):
-    rng = np.random.default_rng(20261004)
-    for it in range(60):
+    # SPIRA_FUZZ_SEED / SPIRA_FUZZ_ITERS: longer one-off campaigns (the defaults are what the suite runs)
+    rng = np.random.default_rng(int(os.environ.get("SPIRA_FUZZ_SEED", "20261004")))
+    for it in range(int(os.environ.get("SPIRA_FUZZ_ITERS", "60"))):
         kind, s, W, H, spp, depth = _case(rng)
         ns, nm, nt = _counts(s)
         prec = "f32" if rng.random() < 0.5 else "f64"
