@@ -67,7 +67,7 @@ def test_path_geometry_bit_exact(gpu, oracle, prec, scene_name):
     s = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3}.get(scene_name, lambda: random_scene(rng, 40, 25))()
     ns, nm, nt = _counts(s)
     W, H, SPP, DEPTH = 320, 180, 8, 8
-    n = 4000
+    n = int(os.environ.get("SPIRA_GEOM_PATHS", "4000"))     # longer one-off campaigns: SPIRA_GEOM_PATHS=200000
     ijs = np.stack([rng.integers(1, W + 1, n), rng.integers(1, H + 1, n), rng.integers(0, SPP, n)], axis=1).astype(np.uint32)
     pg = gpu.make_params(W, H, SPP, DEPTH, ns, nm, nt, seed=42)
     prims, ts, dirs, rad = gpu.trace_paths(*_args(s), pg, ijs, prec)
