@@ -306,6 +306,7 @@ __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<
     // software-pipelined LDS reads: the next sphere's packet is requested before this one is tested, so the
     // ds_read latency overlaps the arithmetic instead of stalling every iteration at s_waitcnt lgkmcnt(0)
     Pack4<T> c_next = sc.sph[0];           // (slot 0 always exists in the LDS image: the block is never empty)
+#pragma unroll 2       // two tests per trip: the packet rotation (c = c_next) turns into register renaming, +1..3 %
     for (uint32_t s = 0; s < sc.n_spheres; ++s) {
         const Pack4<T> c = c_next;
         c_next = sc.sph[s + 1 < sc.n_spheres ? s + 1 : s];
