@@ -327,6 +327,7 @@ __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<
     }
     if (sc.n_triangles) {
         Pack4<T> v0n = sc.tri[0], e1n = sc.tri[1], e2n = sc.tri[2];
+#pragma unroll 2       // as for the spheres: +3 % on S3 in f64, neutral elsewhere
         for (uint32_t i = 0; i < sc.n_triangles; ++i) {
             const Pack4<T> v0 = v0n, e1 = e1n, e2 = e2n;
             const uint32_t nx = i + 1 < sc.n_triangles ? i + 1 : i;
