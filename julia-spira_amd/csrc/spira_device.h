@@ -92,7 +92,7 @@ __device__ __forceinline__ void rng3(const RngKey &k, uint32_t t, T &u0, T &u1, 
 // ------------------------------------------------------------------ scene in LDS
 // Layout of the dynamic LDS block (all offsets multiples of 32 bytes):
 //   sph  : n_spheres   x Pack4<T>  {cx, cy, cz, r*r}   (one ds_read_b128 per sphere test, f32)
-//   tri  : n_triangles x 3 x Pack4<T> {v0,0} {e1,0} {e2,0}
+//   tri  : n_triangles x 3 x Pack4<T> {v0,n.x} {e1,n.y} {e2,n.z}   (n = unit geometric normal)
 //   mat  : n_materials x 2 x Pack4<T> {diffuse, specular} {emission, roughness}
 //   smat : n_spheres   x int32 (0-based material)   tmat : n_triangles x int32
 template <class T> struct SceneLds {
@@ -143,6 +143,10 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
         v0.x = t[0]; v0.y = t[1]; v0.z = t[2]; v0.w = 0;
         e1.x = t[3] - t[0]; e1.y = t[4] - t[1]; e1.z = t[5] - t[2]; e1.w = 0;  // edge1 = v1 - v0, :149
         e2.x = t[6] - t[0]; e2.y = t[7] - t[1]; e2.z = t[8] - t[2]; e2.w = 0;  // edge2 = v2 - v0, :150
+        // the geometric normal depends on the triangle only: normalize(cross(edge1, edge2)), :105-109, evaluated here once
+        // per workgroup instead of once per hit (same operations on the same values, so the same bits)
+        const Vec<T> nrm = normalize(cross(mk<T>(e1.x, e1.y, e1.z), mk<T>(e2.x, e2.y, e2.z)));
+        v0.w = nrm.x; e1.w = nrm.y; e2.w = nrm.z;
         tri[3 * i] = v0; tri[3 * i + 1] = e1; tri[3 * i + 2] = e2;
         tmat[i] = (int)t[9] - 1;
     }
@@ -393,8 +397,7 @@ __device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> po
         n = normalize(pos - mk<T>(c.x, c.y, c.z));                           // :139
     } else if (!BVH || prim < (int)(sc.n_spheres + sc.n_triangles)) {
         int ti = prim - (int)sc.n_spheres;
-        const Pack4<T> e1p = sc.tri[3 * ti + 1], e2p = sc.tri[3 * ti + 2];
-        n = normalize(cross(mk<T>(e1p.x, e1p.y, e1p.z), mk<T>(e2p.x, e2p.y, e2p.z)));   // :105-109
+        n = mk<T>(sc.tri[3 * ti].w, sc.tri[3 * ti + 1].w, sc.tri[3 * ti + 2].w);        // :105-109, precomputed by stage_scene
     } else {
         const Pack4<T> e1p = sc.bvh_tris[3 * (size_t)slot + 1], e2p = sc.bvh_tris[3 * (size_t)slot + 2];
         n = normalize(cross(mk<T>(e1p.x, e1p.y, e1p.z), mk<T>(e2p.x, e2p.y, e2p.z)));   // :105-109
