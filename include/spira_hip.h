@@ -43,7 +43,11 @@
  * spira_last_error() returns a thread-local message.  Host-pointer entry points copy in/out;
  * *_device_* entry points take DEVICE pointers for the outputs (e.g. a torch tensor's
  * data_ptr()) plus the hipStream_t to run on (as void*; NULL = the null stream) and do not
- * synchronise.  There is NO CPU fallback: every render entry point fails with
+ * synchronise.  Streams: all calls on one device share that device's workspaces (ray queues, radiance
+ * buffers, the scene of host-array calls), so the library orders them itself — every call makes its
+ * stream wait (hipStreamWaitEvent) for the end of the previous call on that device, whatever stream that
+ * one ran on.  Calls on different streams are therefore safe without host synchronisation, and run one
+ * after the other on the device.  There is NO CPU fallback: every render entry point fails with
  * SPIRA_E_NO_DEVICE when no HIP device is usable.
  */
 #ifndef SPIRA_HIP_H
@@ -55,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SPIRA_ABI_VERSION 1
+#define SPIRA_ABI_VERSION 2
 
 /* ---- error codes ---- */
 #define SPIRA_OK            0
@@ -172,6 +176,28 @@ int spira_render_device_f64(const double *spheres5, const double *materials8, co
                             const double camera12[12], const spira_params *params,
                             double *d_out_hdr, double *d_out_img, void *stream);
 
+/* ---- scene handles: validate, build (BVH) and upload a scene ONCE, render it many times ----
+ * Replaces the per-render uploads `sphere_data_gpu = MtlArray(sphere_data)` / `material_data_gpu = ...` of
+ * render_hybrid_gpu (src/spira-metal-optimized.jl:1247-1254) after prepare_scene_data (:515-542): the host-array
+ * entry points above re-validate every material index and hash the whole triangle array on every call (to find
+ * the cached BVH), which for an 82 k-triangle mesh is host milliseconds per frame; a handle pays that once.
+ * A handle belongs to the device current at creation (spira_set_device) and to one precision.  With a handle,
+ * params->n_spheres / n_materials / n_triangles are ignored. */
+typedef struct spira_scene spira_scene;
+int spira_scene_create_f32(const float *spheres5, const float *materials8, const float *triangles10,
+                           uint32_t n_spheres, uint32_t n_materials, uint32_t n_triangles, spira_scene **out);
+int spira_scene_create_f64(const double *spheres5, const double *materials8, const double *triangles10,
+                           uint32_t n_spheres, uint32_t n_materials, uint32_t n_triangles, spira_scene **out);
+int spira_scene_destroy(spira_scene *scene);       /* NULL is a no-op; waits for renders still using it */
+int spira_render_scene_f32(const spira_scene *scene, const float camera12[12], const spira_params *params,
+                           float *out_hdr, float *out_img);
+int spira_render_scene_f64(const spira_scene *scene, const double camera12[12], const spira_params *params,
+                           double *out_hdr, double *out_img);
+int spira_render_scene_device_f32(const spira_scene *scene, const float camera12[12], const spira_params *params,
+                                  float *d_out_hdr, float *d_out_img, void *stream);
+int spira_render_scene_device_f64(const spira_scene *scene, const double camera12[12], const spira_params *params,
+                                  double *d_out_hdr, double *d_out_img, void *stream);
+
 /* ---- progressive accumulation (checkpoint / resume / adaptive sampling) ----
  * The contract the reference's kernel was designed for and no host code uses: `current_sample_index`,
  * persisted `rng_states`, `output_hdr_image[p] += L` (src/spira_path_trace_kernel.metal:143-145, :252-268).
@@ -179,7 +205,8 @@ int spira_render_device_f64(const double *spheres5, const double *materials8, co
  * sample order, to sum_rgb (planar 3 x rows x width running sums, caller-owned; zero them before the first
  * call).  image = sum_rgb / total samples; k calls of n samples leave bit for bit the sums of one call of k*n.
  * rng_states (rows*width words, or NULL) is used by SPIRA_SEM_METAL only, whose LCG state runs from sample to
- * sample: written by every call, read when sample0 > 0.  Host pointers, or device pointers + stream. */
+ * sample: written by every call, read when sample0 > 0 — SPIRA_SEM_METAL with sample0 > 0 and rng_states == NULL
+ * is SPIRA_E_INVALID (it would replay the first call's samples).  Host pointers, or device pointers + stream. */
 int spira_accumulate_f32(const float *spheres5, const float *materials8, const float *triangles10,
                          const float camera12[12], const spira_params *params, uint32_t sample0,
                          float *sum_rgb, uint32_t *rng_states);

@@ -36,7 +36,7 @@ template <class T> struct HostPack4 { T x, y, z, w; };
 
 template <class T> inline T bits_to_real(uint32_t u) {
     T r;
-    if (sizeof(T) == 4) { std::memcpy(&r, &u, 4); }
+    if constexpr (sizeof(T) == 4) { std::memcpy(&r, &u, 4); }
     else { uint64_t v = u; std::memcpy(&r, &v, 8); }
     return r;
 }

@@ -8,9 +8,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "spira_sqrt.h"
 
 namespace spira {
+
+// correctly rounded square root: hipcc's default expansion of the builtin (IEEE, like Julia's sqrt)
+__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
 
 constexpr int kBlock = 256;          // 4 waves of 64
 // k_bounce register budget (second __launch_bounds__ argument = minimum waves per SIMD), from a same-device A/B
@@ -57,12 +60,6 @@ template <> struct Bits<double> {
     static __device__ __forceinline__ double from_u32(uint32_t u) { return __longlong_as_double((long long)u); }
     static __device__ __forceinline__ uint32_t to_u32(double f) { return (uint32_t)__double_as_longlong(f); }
 };
-
-#ifdef SPIRA_MARKS      // diagnostic: region markers in the ISA listing (hipcc -S -DSPIRA_MARKS), for per-phase instruction counts
-#define SPIRA_MARK(n) asm volatile("; ===MARK " #n)
-#else
-#define SPIRA_MARK(n)
-#endif
 
 // ------------------------------------------------------------------ counter-based RNG (DESIGN.md "RNG")
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // lowbias32
@@ -430,24 +427,7 @@ __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &
     SegInfo info;
     T t;
     uint32_t slot;
-    // Timing-only diagnostic builds (the results are WRONG; never shipped): -DSPIRA_ABL_NO_HIT / _NO_SAMPLER / _NO_KEY /
-    // _NO_L remove one part of the segment each, -DSPIRA_ABLATE_DOUBLE_HIT repeats the intersection.
-#ifdef SPIRA_ABL_NO_HIT
-    int prim = 1; t = (T)1; slot = 0;
-    asm volatile("" : "+v"(prim));
-#else
-    SPIRA_MARK(hit_begin);
     int prim = closest_hit<T, BVH>(sc, o, d, (T)0.001, t, slot);             // :335
-    SPIRA_MARK(hit_end);
-#endif
-#ifdef SPIRA_ABLATE_DOUBLE_HIT   // diagnostic build only: repeat the intersection on an opaque copy (is the kernel VALU-bound?)
-    {
-        Vec<T> o2 = o; T t2; uint32_t slot2;
-        asm volatile("" : "+v"(o2.x));
-        int prim2 = closest_hit<T, BVH>(sc, o2, d, (T)0.001, t2, slot2);
-        asm volatile("" ::"v"(prim2), "v"(t2));
-    }
-#endif
     info.prim = prim;
     t_out = prim >= 0 ? t : (T)0;
     if (prim < 0) {                                                          // miss: sky, :365-366
@@ -458,7 +438,6 @@ __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &
     }
     const Vec<T> pos = o + d * t;                                            // point_at, :138 / :183
     info.has_contrib = shade_hit<T, BVH>(sc, pos, d, prim, slot, beta, scatter, contrib, pend);
-    SPIRA_MARK(shade_end);
     info.alive = scatter;
     if (scatter) o = pos;
     return info;
@@ -626,9 +605,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
                     q[r] = Bits<T>::to_u32(C.y);
                 }
                 Vec<T> contrib; T t_hit;
-                SPIRA_MARK(front_begin);
                 SegInfo si = segment_front<T, BVH>(sc, o[r], d, beta[r], scatter, contrib, t_hit, pend[r]);
-                SPIRA_MARK(front_end);
                 ++n_seg;
                 // Path radiance L[q].  Bit 31 of the queued path index says "L[q] already holds radiance".  While it
                 // is clear a term is a plain 16-byte STORE (0 + x == x exactly): the load -> add -> store round trip,
@@ -638,7 +615,6 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
                 // the memory side at ~1/17 of the coalesced rate, MI355X_MICROARCH.md.)
                 const uint32_t qi = q[r] & 0x7FFFFFFFu;
                 const bool has_l = (q[r] >> 31) != 0;
-#ifndef SPIRA_ABL_NO_L
                 if (si.has_contrib) {
                     Pack3<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z;
                     if (has_l) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + contrib.x; l.y = l0.y + contrib.y; l.z = l0.z + contrib.z; ++n_rmw; }
@@ -650,18 +626,10 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
                     a.L[qi] = l;
                     ++n_store;
                 }
-#else
-                asm volatile("" ::"v"(contrib.x), "v"(contrib.y), "v"(contrib.z), "v"(has_l));
-#endif
-                SPIRA_MARK(l_end);
                 want = (pend[r].kind == kDiffuse || pend[r].kind == kSpecRough);
                 if (want) {
                     if (!FIRST) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
-#ifdef SPIRA_ABL_NO_KEY
-                    key.hA = pixel; key.hB = sample; key.hBr = 0;
-#else
                     key = rng_key(rc.sA, rc.sB, pixel, sample, a.bounce);
-#endif
                 }
             }
             if (scatter) {
@@ -677,8 +645,6 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
         if (!scatter) continue;        // uniform: the last bounce neither scatters nor enqueues
         wave_lds_sync();
         // ---------------- phase 2: cooperative random_in_unit_sphere() over the wave's work list
-        SPIRA_MARK(phase2_begin);
-#ifndef SPIRA_ABL_NO_SAMPLER
         {
             uint32_t e = lane, t = 1, next = 64;
             bool have = e < n_list;
@@ -710,9 +676,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
                 next += (uint32_t)__popcll(m);
             }
         }
-#endif
         wave_lds_sync();
-        SPIRA_MARK(phase3_begin);
         // ---------------- phase 3: directions, compaction into this wave's region of the out queue
 #pragma unroll
         for (int r = 0; r < R; ++r) {

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -50,15 +51,27 @@ struct DevBuf {
     void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
 };
 
+// A scene resident on one device: the flat arrays exactly as the ABI takes them (+ the BVH of a large mesh).
+// The context owns one (re-uploaded per call, the BVH cached by a hash of the triangle bytes); every
+// spira_scene handle owns one (validated, built and uploaded once by spira_scene_create_*).
+struct SceneStore {
+    DevBuf arrays, bvh_nodes, bvh_tris;
+    uint32_t ns = 0, nm = 0, nt = 0;
+    uint64_t bvh_hash = 0; uint32_t bvh_n = 0; int bvh_prec = 0, bvh_depth = 0;
+    void release() { arrays.release(); bvh_nodes.release(); bvh_tris.release(); bvh_hash = 0; bvh_n = 0; }
+};
+
 struct Ctx {
     bool init = false;
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, scene, out_tmp, trace, bvh_nodes, bvh_tris, rng;
-    uint64_t bvh_hash = 0; uint32_t bvh_n = 0; int bvh_prec = 0, bvh_depth = 0;   // cached tree (keyed by the triangle bytes)
+    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    SceneStore scene;                         // the scene of the current call (host-array entry points)
     spira::Stats *h_stats = nullptr;          // pinned
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_done = nullptr;             // end of the last call that used the workspaces, on whatever stream it ran
+    bool have_done = false;
     std::vector<hipEvent_t> ev_pool;          // profile mode: pairs around bounce launches
     size_t ev_used = 0;
     spira_counters last{};
@@ -70,6 +83,19 @@ struct Ctx {
 constexpr int kMaxDevices = 16;
 Ctx g_ctx[kMaxDevices];
 
+}  // namespace
+
+// The opaque scene handle of the C ABI (spira_scene_create_* / spira_scene_destroy).
+struct spira_scene {
+    uint32_t magic;        // kSceneMagic while alive
+    int device;
+    int prec;              // sizeof(T) the scene was created in
+    SceneStore store;
+};
+
+namespace {
+constexpr uint32_t kSceneMagic = 0x53504952u;   // "SPIR"
+
 int get_ctx(Ctx **out) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -78,6 +104,7 @@ int get_ctx(Ctx **out) {
     if (tl_device < 0 || tl_device >= n || tl_device >= kMaxDevices) return fail(SPIRA_E_INVALID, "device index out of range");
     Ctx &c = g_ctx[tl_device];
     HIP_TRY(hipSetDevice(tl_device));
+    std::lock_guard<std::mutex> init_lock(c.mu);     // two threads must not initialise one context twice
     if (!c.init) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, tl_device));
@@ -88,6 +115,7 @@ int get_ctx(Ctx **out) {
         HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&c.ev_start));
         HIP_TRY(hipEventCreate(&c.ev_stop));
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc((void **)&c.h_stats, sizeof(spira::Stats), hipHostMallocDefault));
         c.init = true;
     }
@@ -108,32 +136,37 @@ uint32_t stripe_rows(uint32_t height, uint32_t sh, uint32_t n, uint32_t r) {
     return rows;
 }
 
+// Scene arrays: pointers, counts, LDS budget and material indices (everything that does not depend on the render parameters).
 template <class T>
-int validate(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
-             uint32_t *rows_out) {
-    if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
-    if (!materials8 || !camera12) return fail(SPIRA_E_INVALID, "materials8 / camera12 is NULL");
-    if (p->n_spheres && !spheres5) return fail(SPIRA_E_INVALID, "spheres5 is NULL");
-    if (p->width < 2 || p->height < 2) return fail(SPIRA_E_INVALID, "width and height must be >= 2 (u = (i-1+rand)/(W-1))");
-    if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "image larger than 2^31 pixels");
-    if (p->spp < 1 || p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "spp out of range [1, 2^24]");
-    if (p->max_depth > SPIRA_MAX_DEPTH) return fail(SPIRA_E_LIMIT, "max_depth > 255");
-    if (p->n_materials < 1) return fail(SPIRA_E_INVALID, "n_materials must be >= 1");
-    uint32_t nt = triangles10 ? p->n_triangles : 0;
-    if (p->n_spheres > SPIRA_MAX_LDS_SPHERES) return fail(SPIRA_E_LIMIT, "more than 1024 spheres");
+int validate_scene(const T *spheres5, const T *materials8, const T *triangles10, uint32_t n_spheres, uint32_t n_materials, uint32_t nt) {
+    if (!materials8) return fail(SPIRA_E_INVALID, "materials8 is NULL");
+    if (n_spheres && !spheres5) return fail(SPIRA_E_INVALID, "spheres5 is NULL");
+    if (n_materials < 1) return fail(SPIRA_E_INVALID, "n_materials must be >= 1");
+    if (n_spheres > SPIRA_MAX_LDS_SPHERES) return fail(SPIRA_E_LIMIT, "more than 1024 spheres");
     if (nt > SPIRA_MAX_TRIANGLES) return fail(SPIRA_E_LIMIT, "more than 2^24 triangles");
-    if (spira::scene_lds_bytes<T>(p->n_spheres, p->n_materials, nt > SPIRA_LDS_TRIANGLES ? 0 : nt) > 120 * 1024)
+    if (spira::scene_lds_bytes<T>(n_spheres, n_materials, nt > SPIRA_LDS_TRIANGLES ? 0 : nt) > 120 * 1024)
         return fail(SPIRA_E_LIMIT, "scene does not fit in LDS");
-    for (uint32_t i = 0; i < p->n_spheres; ++i) {
+    for (uint32_t i = 0; i < n_spheres; ++i) {
         T m = spheres5[5 * (size_t)i + 4];
-        if (!(m >= 1 && m <= (T)p->n_materials) || m != std::floor(m))
+        if (!(m >= 1 && m <= (T)n_materials) || m != std::floor(m))
             return fail(SPIRA_E_INVALID, "sphere material index out of range (1-based, stored as a float)");
     }
     for (uint32_t i = 0; i < nt; ++i) {
         T m = triangles10[10 * (size_t)i + 9];
-        if (!(m >= 1 && m <= (T)p->n_materials) || m != std::floor(m))
+        if (!(m >= 1 && m <= (T)n_materials) || m != std::floor(m))
             return fail(SPIRA_E_INVALID, "triangle material index out of range");
     }
+    return 0;
+}
+
+// Render parameters (nt = triangles actually present in the scene of this call).
+int validate_params(const void *camera12, const spira_params *p, uint32_t nt, uint32_t *rows_out) {
+    if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    if (!camera12) return fail(SPIRA_E_INVALID, "camera12 is NULL");
+    if (p->width < 2 || p->height < 2) return fail(SPIRA_E_INVALID, "width and height must be >= 2 (u = (i-1+rand)/(W-1))");
+    if ((uint64_t)p->width * p->height > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "image larger than 2^31 pixels");
+    if (p->spp < 1 || p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "spp out of range [1, 2^24]");
+    if (p->max_depth > SPIRA_MAX_DEPTH) return fail(SPIRA_E_LIMIT, "max_depth > 255");
     const uint32_t sem = p->flags & SPIRA_SEM_MASK;
     if (sem != SPIRA_SEM_A && sem != SPIRA_SEM_CPU && sem != SPIRA_SEM_METAL) return fail(SPIRA_E_UNSUPPORTED, "unknown integrator semantics");
     if (sem != SPIRA_SEM_A && nt) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_CPU / SPIRA_SEM_METAL are sphere-only, like their sources");
@@ -186,53 +219,70 @@ bool fastdiv_selfcheck(uint32_t d, uint32_t n_max) {
     return true;
 }
 
-// Upload the flat scene arrays into one device buffer; returns device pointers in `g`.  Meshes above
-// SPIRA_LDS_TRIANGLES go through a BVH (built on the host once per distinct triangle array, cached).
 template <class T>
-int upload_scene(Ctx &c, hipStream_t st, const T *spheres5, const T *materials8, const T *triangles10, const spira_params *p,
-                 spira::SceneGlobal<T> &g) {
-    uint32_t nt = triangles10 ? p->n_triangles : 0;
-    const bool use_bvh = nt > SPIRA_LDS_TRIANGLES;
-    const uint32_t nt_lds = use_bvh ? 0 : nt;
-    size_t ns_b = (size_t)p->n_spheres * 5 * sizeof(T), nm_b = (size_t)p->n_materials * 8 * sizeof(T), nt_b = (size_t)nt_lds * 10 * sizeof(T);
+void scene_pointers(const SceneStore &s, spira::SceneGlobal<T> &g) {
+    const bool use_bvh = s.nt > SPIRA_LDS_TRIANGLES;
+    const uint32_t nt_lds = use_bvh ? 0 : s.nt;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    size_t total = up(ns_b) + up(nm_b) + up(nt_b) + 256;
-    if (int rc = c.scene.ensure(total)) return rc;
-    char *base = (char *)c.scene.p;
+    const size_t ns_b = (size_t)s.ns * 5 * sizeof(T), nm_b = (size_t)s.nm * 8 * sizeof(T);
+    char *base = (char *)s.arrays.p;
     g.spheres5 = (const T *)base;
     g.materials8 = (const T *)(base + up(ns_b));
     g.triangles10 = (const T *)(base + up(ns_b) + up(nm_b));
-    g.n_spheres = p->n_spheres; g.n_materials = p->n_materials; g.n_triangles = nt_lds;
-    g.bvh_nodes = nullptr; g.bvh_tris = nullptr; g.n_bvh_tris = 0;
+    g.n_spheres = s.ns; g.n_materials = s.nm; g.n_triangles = nt_lds;
+    g.bvh_nodes = use_bvh ? (const spira::Pack4<T> *)s.bvh_nodes.p : nullptr;
+    g.bvh_tris = use_bvh ? (const spira::Pack4<T> *)s.bvh_tris.p : nullptr;
+    g.n_bvh_tris = use_bvh ? s.nt : 0;
+}
+
+// Upload host arrays into `s`.  The small arrays go asynchronously on `st`; a mesh above SPIRA_LDS_TRIANGLES gets a
+// BVH built on the host (once per distinct triangle array: keyed by a hash of its bytes) and copied synchronously —
+// `prev_done` (the event of the last call that may still be traversing the old tree) is waited for first.
+template <class T>
+int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *spheres5, const T *materials8, const T *triangles10,
+                 uint32_t n_spheres, uint32_t n_materials, uint32_t nt) {
+    const bool use_bvh = nt > SPIRA_LDS_TRIANGLES;
+    const uint32_t nt_lds = use_bvh ? 0 : nt;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t ns_b = (size_t)n_spheres * 5 * sizeof(T), nm_b = (size_t)n_materials * 8 * sizeof(T), nt_b = (size_t)nt_lds * 10 * sizeof(T);
+    if (int rc = s.arrays.ensure(up(ns_b) + up(nm_b) + up(nt_b) + 256)) return rc;
+    s.ns = n_spheres; s.nm = n_materials; s.nt = nt;
+    spira::SceneGlobal<T> g;
+    scene_pointers<T>(s, g);
     if (ns_b) HIP_TRY(hipMemcpyAsync((void *)g.spheres5, spheres5, ns_b, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync((void *)g.materials8, materials8, nm_b, hipMemcpyHostToDevice, st));
     if (nt_b) HIP_TRY(hipMemcpyAsync((void *)g.triangles10, triangles10, nt_b, hipMemcpyHostToDevice, st));
     if (use_bvh) {
         const uint64_t h = spira::bytes_hash64(triangles10, (size_t)nt * 10 * sizeof(T));
-        if (c.bvh_hash != h || c.bvh_n != nt || c.bvh_prec != (int)sizeof(T)) {
+        if (s.bvh_hash != h || s.bvh_n != nt || s.bvh_prec != (int)sizeof(T)) {
             std::vector<spira::HostPack4<T>> nodes, tris;
             int depth = 0;
             if (!spira::bvh_build<T>(triangles10, nt, nodes, tris, &depth)) return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
-            if (int rc = c.bvh_nodes.ensure(nodes.size() * sizeof(nodes[0]))) return rc;
-            if (int rc = c.bvh_tris.ensure(tris.size() * sizeof(tris[0]))) return rc;
+            if (prev_done) HIP_TRY(hipEventSynchronize(prev_done));      // nobody still reads the tree that is about to be replaced
+            if (int rc = s.bvh_nodes.ensure(nodes.size() * sizeof(nodes[0]))) return rc;
+            if (int rc = s.bvh_tris.ensure(tris.size() * sizeof(tris[0]))) return rc;
             // synchronous copies: the host vectors die at the end of this scope
             HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipMemcpy(c.bvh_nodes.p, nodes.data(), nodes.size() * sizeof(nodes[0]), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(c.bvh_tris.p, tris.data(), tris.size() * sizeof(tris[0]), hipMemcpyHostToDevice));
-            c.bvh_hash = h; c.bvh_n = nt; c.bvh_prec = (int)sizeof(T); c.bvh_depth = depth;
+            HIP_TRY(hipMemcpy(s.bvh_nodes.p, nodes.data(), nodes.size() * sizeof(nodes[0]), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(s.bvh_tris.p, tris.data(), tris.size() * sizeof(tris[0]), hipMemcpyHostToDevice));
+            s.bvh_hash = h; s.bvh_n = nt; s.bvh_prec = (int)sizeof(T); s.bvh_depth = depth;
         }
-        g.bvh_nodes = (const spira::Pack4<T> *)c.bvh_nodes.p;
-        g.bvh_tris = (const spira::Pack4<T> *)c.bvh_tris.p;
-        g.n_bvh_tris = nt;
     }
     return 0;
+}
+
+// Launch with a dynamic LDS block; above 64 KB the function has to be told first (up to the CU's 160 KB).
+template <class K, class... Args>
+void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
 }
 
 template <class T, bool FIRST, bool BVH>
 void launch_bounce_r(int R, dim3 grid, size_t lds, hipStream_t st, const spira::BounceArgs<T> &a) {
     switch (R) {
-    case 2: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 2, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
-    default: hipLaunchKernelGGL((spira::k_bounce<T, FIRST, 1, BVH>), grid, dim3(spira::kBlock), lds, st, a); break;
+    case 2: launch_lds(spira::k_bounce<T, FIRST, 2, BVH>, grid, dim3(spira::kBlock), lds, st, a); break;
+    default: launch_lds(spira::k_bounce<T, FIRST, 1, BVH>, grid, dim3(spira::kBlock), lds, st, a); break;
     }
 }
 template <class T, bool FIRST>
@@ -250,20 +300,58 @@ int profile_events(Ctx &c, size_t need) {
     return 0;
 }
 
+// Every call that touches the context's workspaces first makes its stream wait for the previous call's end
+// (which may have run on ANOTHER stream and not have been synchronised): the workspaces are shared per device.
+int order_after_previous(Ctx &c, hipStream_t st) {
+    if (c.have_done) HIP_TRY(hipStreamWaitEvent(st, c.ev_done, 0));
+    return 0;
+}
+int mark_done(Ctx &c, hipStream_t st) {
+    HIP_TRY(hipEventRecord(c.ev_done, st));
+    c.have_done = true;
+    return 0;
+}
+
+// The scene of a call: host arrays (uploaded into the context's store) or a handle (already resident).
 template <class T>
-int render_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
+int acquire_scene(Ctx &c, hipStream_t st, const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10,
+                  const spira_params *p, spira::SceneGlobal<T> &g) {
+    if (h) { scene_pointers<T>(h->store, g); return 0; }
+    const uint32_t nt = triangles10 ? p->n_triangles : 0;
+    if (int rc = scene_upload<T>(c.scene, st, c.have_done ? c.ev_done : nullptr, spheres5, materials8, triangles10, p->n_spheres, p->n_materials, nt)) return rc;
+    scene_pointers<T>(c.scene, g);
+    return 0;
+}
+
+template <class T>
+int check_handle(const spira_scene *h) {
+    if (!h || h->magic != kSceneMagic) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+    if (h->prec != (int)sizeof(T)) return fail(SPIRA_E_INVALID, "scene handle was created in the other precision");
+    if (h->device != tl_device) return fail(SPIRA_E_INVALID, "scene handle belongs to another device (spira_set_device)");
+    return 0;
+}
+
+template <class T>
+int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
                 T *out_hdr, T *out_img, bool out_on_device, void *user_stream,
                 bool progressive = false, uint32_t sample0 = 0, uint32_t *rng_states = nullptr) {
     // progressive: out_hdr is the caller's running SUM (in/out), samples [sample0, sample0 + spp) are added to it
     uint32_t rows = 0;
-    if (int rc = validate<T>(spheres5, materials8, triangles10, camera12, p, &rows)) return rc;
+    if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    if (h) { if (int rc = check_handle<T>(h)) return rc; }
+    else if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, triangles10 ? p->n_triangles : 0)) return rc;
+    if (int rc = validate_params(camera12, p, h ? h->store.nt : (triangles10 ? p->n_triangles : 0), &rows)) return rc;
     if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
     if (progressive && (uint64_t)sample0 + p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "sample0 + spp exceeds 2^24");
+    if (progressive && (p->flags & SPIRA_SEM_MASK) == SPIRA_SEM_METAL && sample0 > 0 && !rng_states)
+        return fail(SPIRA_E_INVALID, "SPIRA_SEM_METAL with sample0 > 0 needs rng_states (the LCG states the previous call left); "
+                                     "without them every call would replay the samples of the first");
     Ctx *cp = nullptr;
     if (int rc = get_ctx(&cp)) return rc;
     Ctx &c = *cp;
     std::lock_guard<std::mutex> lock(c.mu);
     hipStream_t st = out_on_device ? (hipStream_t)user_stream : c.stream;
+    if (int rc = order_after_previous(c, st)) return rc;
 
     const uint32_t W = p->width;
     const uint64_t tile_pixels = (uint64_t)rows * W;
@@ -312,7 +400,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
     if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
 
     spira::BounceArgs<T> a{};
-    if (int rc = upload_scene<T>(c, st, spheres5, materials8, triangles10, p, a.scene)) return rc;
+    if (int rc = acquire_scene<T>(c, st, h, spheres5, materials8, triangles10, p, a.scene)) return rc;
     fill_const<T>(a.rc, camera12, p, rows, slots);
     if (!fastdiv_selfcheck(a.rc.tile_pixels, (uint32_t)batch) || !fastdiv_selfcheck(a.rc.width, a.rc.tile_pixels) ||
         !fastdiv_selfcheck(a.rc.stripe_h ? a.rc.stripe_h : 1, rows))
@@ -366,7 +454,7 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
         // one launch: every lane owns a pixel and walks its spp samples (the LCG state runs through them)
         uint32_t blocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
         a.pass = 0; a.n_first = (uint32_t)tile_pixels;
-        hipLaunchKernelGGL((spira::k_variant_metal<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p, d_rng,
+        launch_lds(spira::k_variant_metal<T>, dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p, d_rng,
                            progressive ? (sample0 > 0 ? 3 : 1) : 0);      // bit 0: continue the sums, bit 1: continue the LCG states
         ++launches;
     } else {
@@ -378,12 +466,12 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
             uint32_t G = 0;
             if (sem == SPIRA_SEM_CPU) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
-                hipLaunchKernelGGL((spira::k_variant_cpu<T>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                launch_lds(spira::k_variant_cpu<T>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 ++launches;
             } else if (mega) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
-                if (a.scene.n_bvh_tris) hipLaunchKernelGGL((spira::k_mega<T, true>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
-                else hipLaunchKernelGGL((spira::k_mega<T, false>), dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                if (a.scene.n_bvh_tris) launch_lds(spira::k_mega<T, true>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                else launch_lds(spira::k_mega<T, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 ++launches;
             } else {
                 geometry(n_first, G, a.cap);
@@ -440,8 +528,9 @@ int render_impl(const T *spheres5, const T *materials8, const T *triangles10, co
         size_t plane3 = 3 * tile_pixels * sizeof(T);
         if (out_hdr) HIP_TRY(hipMemcpyAsync(out_hdr, d_hdr, plane3, hipMemcpyDeviceToHost, st));
         if (out_img) HIP_TRY(hipMemcpyAsync(out_img, d_img, plane3, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
     }
+    if (int rc = mark_done(c, st)) return rc;
+    if (!out_on_device) HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -449,7 +538,9 @@ template <class T>
 int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
                uint32_t n_paths, const uint32_t *ijs, int *prims, T *ts, T *dirs, T *radiance) {
     uint32_t rows = 0;
-    if (int rc = validate<T>(spheres5, materials8, triangles10, camera12, p, &rows)) return rc;
+    if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, triangles10 ? p->n_triangles : 0)) return rc;
+    if (int rc = validate_params(camera12, p, triangles10 ? p->n_triangles : 0, &rows)) return rc;
     if (!n_paths || !ijs || !prims || !ts || !dirs || !radiance) return fail(SPIRA_E_INVALID, "NULL argument");
     if (p->max_depth < 1) return fail(SPIRA_E_INVALID, "max_depth must be >= 1");
     for (uint32_t k = 0; k < n_paths; ++k)
@@ -460,8 +551,9 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     Ctx &c = *cp;
     std::lock_guard<std::mutex> lock(c.mu);
     hipStream_t st = c.stream;
+    if (int rc = order_after_previous(c, st)) return rc;
     spira::BounceArgs<T> a{};
-    if (int rc = upload_scene<T>(c, st, spheres5, materials8, triangles10, p, a.scene)) return rc;
+    if (int rc = acquire_scene<T>(c, st, (const spira_scene *)nullptr, spheres5, materials8, triangles10, p, a.scene)) return rc;
     fill_const<T>(a.rc, camera12, p, rows, 1);
     size_t nseg = (size_t)n_paths * p->max_depth;
     size_t b_ij = ((size_t)n_paths * 3 * sizeof(uint32_t) + 255) & ~(size_t)255;
@@ -480,15 +572,16 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     HIP_TRY(hipMemsetAsync(d_ts, 0, b_ts + b_di, st));
     const size_t lds = spira::scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles);
     const uint32_t sem = p->flags & SPIRA_SEM_MASK;
-    if (sem == SPIRA_SEM_CPU) hipLaunchKernelGGL((spira::k_trace_variant<T, 1>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
-    else if (sem == SPIRA_SEM_METAL) hipLaunchKernelGGL((spira::k_trace_variant<T, 2>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
-    else if (a.scene.n_bvh_tris) hipLaunchKernelGGL((spira::k_trace<T, true>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
-    else hipLaunchKernelGGL((spira::k_trace<T, false>), dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    if (sem == SPIRA_SEM_CPU) launch_lds(spira::k_trace_variant<T, 1>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    else if (sem == SPIRA_SEM_METAL) launch_lds(spira::k_trace_variant<T, 2>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    else if (a.scene.n_bvh_tris) launch_lds(spira::k_trace<T, true>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    else launch_lds(spira::k_trace<T, false>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(prims, d_pr, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ts, d_ts, nseg * sizeof(T), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(dirs, d_di, nseg * 3 * sizeof(T), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(radiance, d_ra, (size_t)n_paths * 3 * sizeof(T), hipMemcpyDeviceToHost, st));
+    if (int rc = mark_done(c, st)) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
@@ -518,6 +611,25 @@ void camera_impl(const T *position, const T *look_at, const T *up, T fov_deg, T 
     HV<T> llc = hsub(hsub(hsub(pos, hdiv(hor, (T)2)), hdiv(ver, (T)2)), hscale(w, focus_dist));
     T o[12] = {pos.x, pos.y, pos.z, llc.x, llc.y, llc.z, hor.x, hor.y, hor.z, ver.x, ver.y, ver.z};
     std::memcpy(out12, o, sizeof o);
+}
+
+template <class T>
+int scene_create(const T *spheres5, const T *materials8, const T *triangles10, uint32_t n_spheres, uint32_t n_materials,
+                        uint32_t n_triangles, spira_scene **out) {
+    if (!out) return fail(SPIRA_E_INVALID, "out is NULL");
+    *out = nullptr;
+    const uint32_t nt = triangles10 ? n_triangles : 0;
+    if (int rc = validate_scene<T>(spheres5, materials8, triangles10, n_spheres, n_materials, nt)) return rc;
+    Ctx *cp = nullptr;
+    if (int rc = get_ctx(&cp)) return rc;              // also selects the device
+    spira_scene *h = new (std::nothrow) spira_scene();
+    if (!h) return fail(SPIRA_E_HIP, "out of host memory");
+    h->magic = kSceneMagic; h->device = tl_device; h->prec = (int)sizeof(T);
+    int rc = scene_upload<T>(h->store, nullptr, nullptr, spheres5, materials8, triangles10, n_spheres, n_materials, nt);
+    if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(SPIRA_E_HIP, "hipStreamSynchronize failed after the scene upload");
+    if (rc) { h->store.release(); h->magic = 0; delete h; return rc; }
+    *out = h;
+    return 0;
 }
 
 }  // namespace
@@ -580,10 +692,11 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); }
-        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.bvh_nodes.release(); c.bvh_tris.release(); c.rng.release(); c.bvh_hash = 0; c.bvh_n = 0;
+        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
-        (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop);
+        (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop); (void)hipEventDestroy(c.ev_done);
+        c.have_done = false;
         (void)hipHostFree(c.h_stats);
         (void)hipStreamDestroy(c.stream);
         c.init = false; c.last_valid = false;
@@ -604,39 +717,74 @@ int spira_camera_lookat_f64(const double position[3], const double look_at[3], c
 }
 
 int spira_render_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, float *out_hdr, float *out_img) {
-    return render_impl<float>(s, m, t, cam, p, out_hdr, out_img, false, nullptr);
+    return render_impl<float>(nullptr, s, m, t, cam, p, out_hdr, out_img, false, nullptr);
 }
 int spira_render_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, double *out_hdr, double *out_img) {
-    return render_impl<double>(s, m, t, cam, p, out_hdr, out_img, false, nullptr);
+    return render_impl<double>(nullptr, s, m, t, cam, p, out_hdr, out_img, false, nullptr);
 }
 int spira_render_device_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, float *d_hdr,
                             float *d_img, void *stream) {
-    return render_impl<float>(s, m, t, cam, p, d_hdr, d_img, true, stream);
+    return render_impl<float>(nullptr, s, m, t, cam, p, d_hdr, d_img, true, stream);
 }
 int spira_render_device_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, double *d_hdr,
                             double *d_img, void *stream) {
-    return render_impl<double>(s, m, t, cam, p, d_hdr, d_img, true, stream);
+    return render_impl<double>(nullptr, s, m, t, cam, p, d_hdr, d_img, true, stream);
 }
 
 int spira_accumulate_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t sample0,
                          float *sum_rgb, uint32_t *rng_states) {
     if (!sum_rgb) return fail(SPIRA_E_INVALID, "sum_rgb is NULL");
-    return render_impl<float>(s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
+    return render_impl<float>(nullptr, s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
 }
 int spira_accumulate_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t sample0,
                          double *sum_rgb, uint32_t *rng_states) {
     if (!sum_rgb) return fail(SPIRA_E_INVALID, "sum_rgb is NULL");
-    return render_impl<double>(s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
+    return render_impl<double>(nullptr, s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
 }
 int spira_accumulate_device_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t sample0,
                                 float *d_sum_rgb, uint32_t *d_rng_states, void *stream) {
     if (!d_sum_rgb) return fail(SPIRA_E_INVALID, "d_sum_rgb is NULL");
-    return render_impl<float>(s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
+    return render_impl<float>(nullptr, s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
 }
 int spira_accumulate_device_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t sample0,
                                 double *d_sum_rgb, uint32_t *d_rng_states, void *stream) {
     if (!d_sum_rgb) return fail(SPIRA_E_INVALID, "d_sum_rgb is NULL");
-    return render_impl<double>(s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
+    return render_impl<double>(nullptr, s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
+}
+
+// ---- scene handles: validate + build + upload once, render many times
+int spira_scene_create_f32(const float *spheres5, const float *materials8, const float *triangles10, uint32_t n_spheres, uint32_t n_materials,
+                           uint32_t n_triangles, spira_scene **out) {
+    return scene_create<float>(spheres5, materials8, triangles10, n_spheres, n_materials, n_triangles, out);
+}
+int spira_scene_create_f64(const double *spheres5, const double *materials8, const double *triangles10, uint32_t n_spheres, uint32_t n_materials,
+                           uint32_t n_triangles, spira_scene **out) {
+    return scene_create<double>(spheres5, materials8, triangles10, n_spheres, n_materials, n_triangles, out);
+}
+int spira_scene_destroy(spira_scene *scene) {
+    if (!scene) return 0;
+    if (scene->magic != kSceneMagic) return fail(SPIRA_E_INVALID, "scene handle was already destroyed");
+    if (hipSetDevice(scene->device) != hipSuccess) return fail(SPIRA_E_HIP, "hipSetDevice failed");
+    scene->store.release();                            // hipFree waits for work that still reads the buffers
+    scene->magic = 0;
+    delete scene;
+    return 0;
+}
+int spira_render_scene_f32(const spira_scene *scene, const float cam[12], const spira_params *p, float *out_hdr, float *out_img) {
+    if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+    return render_impl<float>(scene, nullptr, nullptr, nullptr, cam, p, out_hdr, out_img, false, nullptr);
+}
+int spira_render_scene_f64(const spira_scene *scene, const double cam[12], const spira_params *p, double *out_hdr, double *out_img) {
+    if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+    return render_impl<double>(scene, nullptr, nullptr, nullptr, cam, p, out_hdr, out_img, false, nullptr);
+}
+int spira_render_scene_device_f32(const spira_scene *scene, const float cam[12], const spira_params *p, float *d_hdr, float *d_img, void *stream) {
+    if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+    return render_impl<float>(scene, nullptr, nullptr, nullptr, cam, p, d_hdr, d_img, true, stream);
+}
+int spira_render_scene_device_f64(const spira_scene *scene, const double cam[12], const spira_params *p, double *d_hdr, double *d_img, void *stream) {
+    if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+    return render_impl<double>(scene, nullptr, nullptr, nullptr, cam, p, d_hdr, d_img, true, stream);
 }
 
 int spira_trace_paths_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t n_paths,

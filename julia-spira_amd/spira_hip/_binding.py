@@ -26,7 +26,8 @@ EXPORTS = [
     "spira_shutdown", "spira_camera_lookat_f32", "spira_camera_lookat_f64", "spira_render_f32", "spira_render_f64",
     "spira_render_device_f32", "spira_render_device_f64", "spira_trace_paths_f32", "spira_trace_paths_f64",
     "spira_tonemap_f32", "spira_stripe_rows", "spira_accumulate_f32", "spira_accumulate_f64", "spira_accumulate_device_f32",
-    "spira_accumulate_device_f64",
+    "spira_accumulate_device_f64", "spira_scene_create_f32", "spira_scene_create_f64", "spira_scene_destroy",
+    "spira_render_scene_f32", "spira_render_scene_f64", "spira_render_scene_device_f32", "spira_render_scene_device_f64",
 ]
 
 
@@ -162,6 +163,53 @@ def render_device(spheres5, materials8, triangles10, camera12, params, d_hdr_ptr
     fn = lib().spira_render_device_f32 if prec == "f32" else lib().spira_render_device_f64
     _check(fn(sp, mp, tp, cp, C.byref(params), C.c_void_p(d_hdr_ptr or None), C.c_void_p(d_img_ptr or None),
               C.c_void_p(stream_ptr or None)))
+
+
+class Scene:
+    """A scene resident on the current device (spira_scene_create_* / spira_scene_destroy): validated, its BVH built
+    and everything uploaded once.  Use as a context manager or call destroy()."""
+
+    def __init__(self, spheres5, materials8, triangles10=None, prec="f32"):
+        npdt, _ = _dt(prec)
+        s, sp = _arr(spheres5, npdt)
+        m, mp = _arr(materials8, npdt)
+        t, tp = _arr(triangles10, npdt)
+        self.prec = prec
+        self.counts = (0 if s is None else len(s), len(m), 0 if t is None else len(t))
+        self._h = C.c_void_p()
+        fn = lib().spira_scene_create_f32 if prec == "f32" else lib().spira_scene_create_f64
+        _check(fn(sp, mp, tp, C.c_uint32(self.counts[0]), C.c_uint32(self.counts[1]), C.c_uint32(self.counts[2]), C.byref(self._h)))
+
+    def destroy(self):
+        if self._h:
+            _check(lib().spira_scene_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+
+    def params(self, width, height, spp, max_depth, **kw):
+        return make_params(width, height, spp, max_depth, *self.counts, **kw)
+
+    def render(self, camera12, params, want_hdr=True, want_img=False):
+        npdt, _ = _dt(self.prec)
+        c, cp = _arr(camera12, npdt)
+        rows = params.rows if params.rows else params.height
+        hdr = np.empty((3, rows, params.width), dtype=npdt) if want_hdr else None
+        img = np.empty((3, rows, params.width), dtype=npdt) if want_img else None
+        fn = lib().spira_render_scene_f32 if self.prec == "f32" else lib().spira_render_scene_f64
+        _check(fn(self._h, cp, C.byref(params), hdr.ctypes.data_as(C.c_void_p) if want_hdr else None,
+                  img.ctypes.data_as(C.c_void_p) if want_img else None))
+        return hdr, img
+
+    def render_device(self, camera12, params, d_hdr_ptr, d_img_ptr, stream_ptr):
+        npdt, _ = _dt(self.prec)
+        c, cp = _arr(camera12, npdt)
+        fn = lib().spira_render_scene_device_f32 if self.prec == "f32" else lib().spira_render_scene_device_f64
+        _check(fn(self._h, cp, C.byref(params), C.c_void_p(d_hdr_ptr or None), C.c_void_p(d_img_ptr or None), C.c_void_p(stream_ptr or None)))
 
 
 def accumulate(spheres5, materials8, triangles10, camera12, params, sample0, sum_rgb, rng_states=None, prec="f32"):

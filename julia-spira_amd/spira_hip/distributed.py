@@ -1,5 +1,5 @@
 """Multi-GPU sharding of the path: one process per GPU, image rows dealt to the
-ranks as interleaved stripes, NO data-path collective while rendering, one all-gather of the tiles
+ranks as interleaved stripes, NO data-path collective while rendering, one gather of the tiles
 at the end (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).
 
 The RNG is keyed by the global pixel, so the assembled image is bit-identical for any world
@@ -60,12 +60,22 @@ def assemble(tiles, height, world, stripe_h=DEFAULT_STRIPE_H):
     return out
 
 
-def gather_image(local_tile, height, stripe_h=DEFAULT_STRIPE_H, dst=0):
-    """All-gather every rank's tile (torch tensor [3, rows_r, W]) and assemble [3, height, W] on `dst`.
+def collective_mode(backend, device_type):
+    """Which collective brings the tiles to `dst`, decided from facts every rank shares (never by catching an error on one
+    rank and retrying with another collective: a rank-local failure would leave the ranks inside different collectives)."""
+    if backend == "nccl" or device_type == "cpu":
+        return "gather"           # RCCL (ncclSend/ncclRecv under the hood) and gloo-on-CPU implement gather
+    return "all_gather"           # gloo with device tensors (the one-GPU rehearsal): gather is not implemented there
 
-    One collective per frame: tiles are padded to the largest tile and land in one [world, 3, rows, W]
-    buffer (ncclAllGather; 3.1 MB per GPU at 1080p / 8 GPUs); the row permutation back to image order is one
-    indexed copy with index tensors built once per geometry.  Returns None off `dst`.
+
+def gather_image(local_tile, height, stripe_h=DEFAULT_STRIPE_H, dst=0):
+    """Gather every rank's tile (torch tensor [3, rows_r, W]) on `dst` and assemble [3, height, W] there.
+
+    One collective per frame: tiles are padded to the largest tile and land in one [world, 3, rows, W] buffer on `dst`
+    (3.1 MB per GPU at 1080p / 8 GPUs in f32).  With RCCL a gather is world-1 point-to-point transfers that arrive over
+    separate xGMI links at once; an all-gather would also ship every tile to every other rank (7x the traffic on a ring)
+    and is used only where the backend has no gather for the tensor's device.  The row permutation back to image order is
+    one indexed copy with index tensors built once per geometry.  Returns None off `dst`.
     """
     import torch
     import torch.distributed as dist
@@ -79,25 +89,18 @@ def gather_image(local_tile, height, stripe_h=DEFAULT_STRIPE_H, dst=0):
         mr = max_rows(height, world, stripe_h)
         sr, sl = source_of_rows(height, world, stripe_h)
         plan = dict(mr=mr, stacked=local_tile.new_empty((world, 3, mr, W)), padded=local_tile.new_zeros((3, mr, W)),
-                    src_rank=torch.as_tensor(sr, device=local_tile.device), src_row=torch.as_tensor(sl, device=local_tile.device))
+                    src_rank=torch.as_tensor(sr, device=local_tile.device), src_row=torch.as_tensor(sl, device=local_tile.device),
+                    mode=collective_mode(dist.get_backend(), local_tile.device.type))
         _plans[key] = plan
     if local_tile.shape[1] == plan["mr"]:
         padded = local_tile.contiguous()
     else:
         padded = plan["padded"]
         padded[:, :local_tile.shape[1]] = local_tile
-    # gather: only `dst` needs the tiles, and on xGMI the world-1 point-to-point transfers arrive over separate
-    # links at once (an all-gather would also ship every tile to every other rank: 7x the traffic on a ring)
-    if plan.get("mode", "gather") == "gather":
-        try:
-            dist.gather(padded, list(plan["stacked"].unbind(0)) if rank == dst else None, dst=dst)
-        except (RuntimeError, NotImplementedError, ValueError):    # a backend without gather: all-gather is universal
-            plan["mode"] = "all_gather"
-    if plan.get("mode") == "all_gather":
-        try:
-            dist.all_gather_into_tensor(plan["stacked"], padded)
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather(list(plan["stacked"].unbind(0)), padded)
+    if plan["mode"] == "gather":
+        dist.gather(padded, list(plan["stacked"].unbind(0)) if rank == dst else None, dst=dst)
+    else:
+        dist.all_gather(list(plan["stacked"].unbind(0)), padded)
     if rank != dst:
         return None
     return plan["stacked"][plan["src_rank"], :, plan["src_row"]].permute(1, 0, 2).contiguous()

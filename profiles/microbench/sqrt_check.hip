@@ -2,7 +2,7 @@
 // (sqrt_core) against the compiler's correctly rounded expansion, over ALL 2^32 Float32 bit patterns and over 2^32
 // Float64 inputs (every exponent, hashed mantissas).  Prints the number of mismatches (must be 0) and how many
 // inputs took the fast path.   build: hipcc -O3 --offload-arch=gfx950 -I../../julia-spira_amd/csrc sqrt_check.hip -o sqrt_check
-#include "spira_sqrt.h"
+#include "spira_sqrt_experiment.h"
 #include <cstdio>
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) { z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }

@@ -22,7 +22,7 @@ def test_exports_match_header(binding):
     for name in sorted(declared):
         assert hasattr(lib, name), "libspira_hip.so does not export %s" % name
     assert declared == set(binding.EXPORTS)
-    assert lib.spira_abi_version() == 1
+    assert lib.spira_abi_version() == 2
 
 
 def test_struct_sizes(binding):

@@ -1,0 +1,132 @@
+"""GPU (MI355X): host-runtime contracts of the C ABI — stream ordering of the shared workspaces, scene handles,
+large LDS scenes, progressive accumulation against the ORACLE (not only against the HIP one-shot)."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from spira_hip import scenes
+from test_gpu_parity import _args, _close, _counts, random_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_streams_without_host_sync(gpu):
+    """every call on a device shares one set of workspaces.  A device-pointer render on a side stream
+    immediately followed — no synchronisation — by renders on other streams (the library's own, another side stream, with
+    a DIFFERENT scene and size) must all produce the images they produce when run alone."""
+    import torch
+    s1, s3 = scenes.scene_s1(), scenes.scene_s3()
+    jobs = [(s1, 640, 360, 16, 6, "f32"), (s3, 320, 180, 8, 8, "f64"), (s1, 256, 144, 32, 5, "f64"), (s3, 480, 270, 4, 8, "f32")]
+    want = []
+    for (s, W, H, spp, d, prec) in jobs:
+        ns, nm, nt = _counts(s)
+        hdr, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, d, ns, nm, nt, flags=gpu.POST_NONE, seed=5), prec)
+        want.append(hdr)
+    for rep in range(3):
+        streams = [torch.cuda.Stream() for _ in jobs]
+        outs = [torch.empty((3, H, W), dtype=torch.float32 if prec == "f32" else torch.float64, device="cuda:0") for (_, W, H, _, _, prec) in jobs]
+        for (s, W, H, spp, d, prec), st, out in zip(jobs, streams, outs):
+            ns, nm, nt = _counts(s)
+            gpu.render_device(*_args(s), gpu.make_params(W, H, spp, d, ns, nm, nt, flags=gpu.POST_NONE, seed=5), out.data_ptr(), 0, st.cuda_stream, prec)
+        # a host-pointer render on the library's own stream, still without any synchronisation of the side streams
+        ns, nm, nt = _counts(s3)
+        host, _ = gpu.render(*_args(s3), gpu.make_params(200, 100, 8, 8, ns, nm, nt, flags=gpu.POST_NONE, seed=5), "f32")
+        for st in streams:
+            st.synchronize()
+        for out, w in zip(outs, want):
+            assert np.array_equal(out.cpu().numpy(), w)
+        if rep == 0:
+            host0 = host
+        assert np.array_equal(host, host0)
+
+
+def test_scene_handle_equals_arrays_and_is_reusable(gpu):
+    s = scenes.scene_s4(level=4)      # 5 120 triangles: BVH path
+    ns, nm, nt = _counts(s)
+    for prec in ("f32", "f64"):
+        ref, _ = gpu.render(*_args(s), gpu.make_params(160, 90, 4, 6, ns, nm, nt, seed=9), prec)
+        with gpu.Scene(s["spheres5"], s["materials8"], s["triangles10"], prec) as sc:
+            assert sc.counts == (ns, nm, nt)
+            for _ in range(3):
+                hdr, _ = sc.render(s["camera12"], sc.params(160, 90, 4, 6, seed=9))
+                assert np.array_equal(hdr, ref)
+            # interleave a host-array render of ANOTHER scene: the handle's buffers are its own
+            s1 = scenes.scene_s1()
+            gpu.render(*_args(s1), gpu.make_params(64, 36, 2, 4, 5, 5, 0, seed=1), prec)
+            hdr, _ = sc.render(s["camera12"], sc.params(160, 90, 4, 6, seed=9))
+            assert np.array_equal(hdr, ref)
+            other = "f64" if prec == "f32" else "f32"
+            cam = np.ascontiguousarray(s["camera12"], dtype=np.float64 if other == "f64" else np.float32)
+            fn = gpu.lib().spira_render_scene_f64 if other == "f64" else gpu.lib().spira_render_scene_f32
+            p = sc.params(16, 9, 1, 1)
+            out = np.zeros((3, 9, 16), dtype=cam.dtype)
+            assert fn(sc._h, cam.ctypes.data_as(C.c_void_p), C.byref(p), out.ctypes.data_as(C.c_void_p), None) == -1   # wrong precision
+    with pytest.raises(gpu.SpiraError):
+        bad = s["spheres5"].copy(); bad[0, 4] = 99
+        gpu.Scene(bad, s["materials8"], None, "f32")
+
+
+def test_scene_handle_removes_per_frame_host_work(gpu):
+    """Config-5 mesh (81 920 triangles): per-call host time of the array entry point (re-validates every material index and
+    hashes 3.3 / 6.5 MB of triangles to find the cached tree) against a handle.  Reported, and the handle must not be slower."""
+    s = scenes.scene_s4()
+    ns, nm, nt = _counts(s)
+    p = gpu.make_params(256, 144, 1, 2, ns, nm, nt, seed=3)
+    for prec in ("f32", "f64"):
+        gpu.render(*_args(s), p, prec)       # builds + caches the tree
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ref, _ = gpu.render(*_args(s), p, prec)
+        t_arr = (time.perf_counter() - t0) / 5
+        with gpu.Scene(s["spheres5"], s["materials8"], s["triangles10"], prec) as sc:
+            sc.render(s["camera12"], p)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                hdr, _ = sc.render(s["camera12"], p)
+            t_h = (time.perf_counter() - t0) / 5
+            assert np.array_equal(hdr, ref)
+        print("config-5 scene, %s: %.2f ms per call with host arrays, %.2f ms with a scene handle" % (prec, t_arr * 1e3, t_h * 1e3))
+        assert t_h < t_arr
+
+
+@pytest.mark.parametrize("kernel", ["wavefront", "mega"])
+def test_large_lds_scene_1024_spheres(gpu, oracle, kernel):
+    """SPIRA_MAX_LDS_SPHERES spheres and 400 materials in Float64: 32 KB + 4 KB + 25 KB of scene (+ 16 KB of work lists) —
+    a dynamic-LDS launch above 64 KB — against the oracle."""
+    rng = np.random.default_rng(3)
+    s = random_scene(rng, 1024, 8, n_mats=400)
+    ns, nm, nt = _counts(s)
+    flags = gpu.KERNEL_MEGA if kernel == "mega" else gpu.KERNEL_WAVEFRONT
+    for prec in ("f64", "f32"):
+        hdr, _ = gpu.render(*_args(s), gpu.make_params(96, 54, 2, 5, ns, nm, nt, flags=flags, seed=21), prec)
+        ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(96, 54, 2, 5, ns, nm, nt, seed=21), prec)
+        assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg, prec
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_progressive_sums_match_oracle(gpu, oracle, prec):
+    """k calls of n samples against the ORACLE's one render of k*n samples (r1 only compared with the HIP one-shot)."""
+    s = scenes.scene_s2()
+    ns, nm, nt = _counts(s)
+    W, H, depth, total = 120, 68, 6, 20
+    npdt = np.float32 if prec == "f32" else np.float64
+    ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(W, H, total, depth, ns, nm, nt, seed=31), prec)
+    for chunks in ([20], [7, 7, 6], [1, 19]):
+        sums = np.zeros((3, H, W), dtype=npdt)
+        s0, seg = 0, 0
+        for n in chunks:
+            gpu.accumulate(*_args(s), gpu.make_params(W, H, n, depth, ns, nm, nt, seed=31), s0, sums, None, prec)
+            seg += gpu.counters()["segments"]
+            s0 += n
+        assert _close(sums / npdt(total), ohdr)[0] == 0 and seg == oseg, chunks
+
+
+def test_progressive_metal_needs_rng_states(gpu):
+    """SPIRA_SEM_METAL with sample0 > 0 and no rng_states would replay the first call's samples: SPIRA_E_INVALID."""
+    s = scenes.scene_s1()
+    sums = np.zeros((3, 36, 64), dtype=np.float32)
+    gpu.accumulate(s["spheres5"], s["materials8"], None, s["camera12"], gpu.make_params(64, 36, 2, 4, 5, 5, 0, flags=gpu.SEM_METAL, seed=1), 0, sums, None, "f32")
+    with pytest.raises(gpu.SpiraError, match="rng_states"):
+        gpu.accumulate(s["spheres5"], s["materials8"], None, s["camera12"], gpu.make_params(64, 36, 2, 4, 5, 5, 0, flags=gpu.SEM_METAL, seed=1), 2, sums, None, "f32")
