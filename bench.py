@@ -6,12 +6,19 @@ A "step" is one whole render of the workload.  At N=1 the workload is BASELINE c
 src/spira-metal-optimized.jl:429-510 with main()'s camera :1499-1505), synthetic by construction.
 At N>1 the frame is tile-sharded over the ranks (interleaved 8-row stripes, one process per GPU,
 no collective while rendering, ONE RCCL gather of the tiles per step) and spp = 64*N, so the
-per-GPU work is fixed ("weak").  Scene and camera are uploaded per render (a few hundred bytes);
-outputs stay in HBM.
+per-GPU work is fixed ("weak").  `--config c4` is BASELINE configs[3] instead: spp 256 in TOTAL at any
+N ("strong"); `--config c5` is configs[4] (mesh scene, depth 12).  Scene and camera are uploaded per
+render (a few hundred bytes); outputs stay in HBM.
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (k_bounce) from a
-separate, event-bracketed render after the timed region; `cpu_baseline` times the CPU oracle
-(a port: the Julia reference cannot run here) on the host cores, N=1 only.
+Prints ONE JSON line on rank 0.
+  roofline      the dominant kernel (k_path: one launch per pass) against the HBM roofline: algorithmic bytes from the
+                device counters of the LAST TIMED step divided by that step's own kernel time (HIP events the library
+                records around every k_path launch on the render stream) — so avg_launch_ms * launches <= ms_per_step.
+                `valu` (from the committed PMC summary of the same command) is the VALU-issue side; `bound` names
+                whichever fraction is higher.
+  stress        the same frame on S3 (closed box: every path runs all 8 segments), N=1 only.
+  organisations the round-1 per-bounce organisation and the megakernel on the same workload, N=1 only (informational).
+  cpu_baseline  the CPU oracle (a port: the Julia reference cannot run here) on the host cores, N=1 only.
 """
 import argparse
 import json
@@ -23,13 +30,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(ROOT, "julia-spira_amd"), os.path.join(ROOT, "oracle")]
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+SCENE_DESC = {"s1": "create_scene() of src/spira-metal-optimized.jl", "s2": "create_scene() of examples/julia-raytracer.jl",
+              "s3": "S1 inside a closed box", "s4": "create_scene_with_obj() of examples/julia-raytracer.jl with an 81 920-triangle procedural mesh (BVH)"}
+CONFIGS = {   # BASELINE.json configs[2..4]: scene, spp, depth, spp is per GPU (weak) or in total (strong)
+    "c3": dict(scene="s1", spp=64, depth=8, scaling="weak", name="BASELINE configs[2]"),
+    "c4": dict(scene="s1", spp=256, depth=8, scaling="strong", name="BASELINE configs[3]"),
+    "c5": dict(scene="s4", spp=64, depth=12, scaling="weak", name="BASELINE configs[4]"),
+}
 
 
-def algorithmic_bytes(c, prec_bytes):
-    """HBM bytes the wavefront formulation must move (DESIGN.md "Roofline"), from device counters:
-    every enqueued ray is written once and read once (10 values), a radiance term is a 3-value store, or a
-    read-modify-write (2 x 3 values) when the path already holds radiance."""
-    return (2 * 10 * c["rays_enqueued"] + 3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes
+def algorithmic_bytes(c, prec_bytes, kernel):
+    """HBM bytes the wavefront formulation must move (DESIGN.md "Roofline"), from device counters: every queued packet is
+    written once and read once, a radiance term is a 3-value store, or a read-modify-write (2 x 3 values) when the path
+    already holds radiance.  Packet: 10 values (+ a 4-byte hit reference in the Float32 hit queues of k_path)."""
+    packet = 10 * prec_bytes + (4 if (kernel == "wavefront" and prec_bytes == 4) else 0)
+    return 2 * packet * c["rays_enqueued"] + (3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes
 
 
 def host_cpu_share():
@@ -47,21 +62,54 @@ def host_cpu_share():
     return n
 
 
+def roofline_record(c, prec, kernel, scene, is_headline_shape):
+    """Roofline of the dominant kernel from one render's counters (spira_get_counters)."""
+    pb = 4 if prec == "f32" else 8
+    nbytes = algorithmic_bytes(c, pb, kernel)
+    launches = max(1, c["bounce_launches"])
+    kms = c["bounce_kernel_ms"]
+    achieved = nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    rec = {"bound": "hbm", "kernel": "k_path" if kernel == "wavefront" else "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+           "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(kms / launches, 5), "launches": launches,
+           "kernel_ms_per_step": round(kms, 4), "bytes_per_sample": round(nbytes / c["samples"], 2),
+           "segments_per_sample": round(c["segments"] / c["samples"], 4), "packets_per_sample": round(c["rays_enqueued"] / c["samples"], 4),
+           "kernel_share_of_step": round(kms / max(c["kernel_ms"], 1e-9), 4), "valu": None}
+    tag = "%s_%s" % (scene, prec) if kernel == "wavefront" else "%s_%s_%s" % (kernel, scene, prec)
+    tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
+    if is_headline_shape and os.path.exists(tfile):      # PMC figures of this same command (profiles/run_profile.sh)
+        tj = json.load(open(tfile))
+        if tj.get("kernel") == rec["kernel"]:
+            rec["traffic"], rec["traffic_source"] = round(tj["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(tfile)
+            if tj.get("valu"):
+                v = tj["valu"]
+                rec["valu"] = {"busy_frac": v["busy_frac"], "lane_utilisation": v["lane_utilisation"], "wave_cycle_shares": v.get("wave_cycle_shares"),
+                               "what": "share of all SIMD cycles in which the VALU is executing an instruction of this kernel "
+                                       "(SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), rocprofv3 --pmc)",
+                               "source": rec["traffic_source"]}
+                if v["busy_frac"] > rec["frac"]:
+                    rec["bound"] = "valu"
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json configuration (c3 = configs[2], the headline)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64, help="samples per pixel PER GPU (total = spp * gpus)")
-    ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--scene", default="s1", choices=["s1", "s2", "s3", "s4"])
-    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "mega"])
+    ap.add_argument("--spp", type=int, default=None, help="override the configuration's spp")
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--scene", default=None, choices=["s1", "s2", "s3", "s4"])
+    ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "bounce", "mega"],
+                    help="wavefront = persistent hit-queue kernel (default); bounce = round-1 per-bounce launches; mega = one lane per path")
     ap.add_argument("--prec", default="f64", choices=["f32", "f64"],
                     help="arithmetic type; f64 is the precision of the parity oracle examples/julia-raytracer.jl (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the informational run in the other precision")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stress scene and the other kernel organisations")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="all ranks use GPU 0 and the gloo backend (not a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -88,19 +136,31 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
-    W, H, depth = args.width, args.height, args.depth
-    spp_total = args.spp * world
-    s = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3, "s4": scenes.scene_s4}[args.scene]()
-    sc = (s["spheres5"], s["materials8"], s["triangles10"], s["camera12"])
-    ns, nm = len(s["spheres5"]), len(s["materials8"])
-    nt = 0 if s["triangles10"] is None else len(s["triangles10"])
-    kflag = B.KERNEL_MEGA if args.kernel == "mega" else B.KERNEL_WAVEFRONT
+    cfg = CONFIGS[args.config]
+    scene_name = args.scene or cfg["scene"]
+    W, H = args.width, args.height
+    depth = args.depth if args.depth is not None else cfg["depth"]
+    spp_cfg = args.spp if args.spp is not None else cfg["spp"]
+    spp_total = spp_cfg * world if cfg["scaling"] == "weak" else spp_cfg
+    builders = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3, "s4": scenes.scene_s4}
+    kflags = {"wavefront": B.KERNEL_WAVEFRONT, "bounce": B.KERNEL_BOUNCE, "mega": B.KERNEL_MEGA}
+    seed = scenes.seed_for({"c3": 3, "c4": 4, "c5": 5}[args.config])
     tile = D.tile_params(H, world, rank)
     rows = tile["rows"] or H
-    params = B.make_params(W, H, spp_total, depth, ns, nm, nt, flags=kflag | B.POST_NONE, seed=scenes.seed_for(3), **tile)
-    tdt = torch.float32 if args.prec == "f32" else torch.float64
-    out = torch.empty((3, rows, W), dtype=tdt, device="cuda")
     stream = torch.cuda.current_stream()
+    headline_shape = (W, H, spp_total, depth, world) == (1920, 1080, 64, 8, 1)
+
+    def workload(name):
+        s = builders[name]()
+        sc = (s["spheres5"], s["materials8"], s["triangles10"], s["camera12"])
+        ns, nm = len(s["spheres5"]), len(s["materials8"])
+        nt = 0 if s["triangles10"] is None else len(s["triangles10"])
+        return sc, (ns, nm, nt)
+
+    sc, counts = workload(scene_name)
+    params = B.make_params(W, H, spp_total, depth, *counts, flags=kflags[args.kernel] | B.POST_NONE, seed=seed, **tile)
+    tdt = {"f32": torch.float32, "f64": torch.float64}
+    out = torch.empty((3, rows, W), dtype=tdt[args.prec], device="cuda")
 
     def step():
         B.render_device(*sc, params, out.data_ptr(), 0, stream.cuda_stream, args.prec)
@@ -126,90 +186,104 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    c_timed = B.counters()
+    c_timed = B.counters()          # device counters + event times of the LAST timed step on this rank
     samples_per_step = W * H * spp_total
     value = samples_per_step * args.steps / dt / 1e6
+
+    def side_run(scene, kernel, prec, reps=3):
+        """An extra, untimed-region measurement on rank 0: (Msamples/s, ms per step, roofline record)."""
+        sc2, counts2 = workload(scene)
+        fl = kflags[kernel] | B.POST_NONE
+        pp = B.make_params(W, H, spp_total, depth, *counts2, flags=fl, seed=seed, **tile)
+        o2 = torch.empty((3, rows, W), dtype=tdt[prec], device="cuda")
+        B.render_device(*sc2, pp, o2.data_ptr(), 0, stream.cuda_stream, prec)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            B.render_device(*sc2, pp, o2.data_ptr(), 0, stream.cuda_stream, prec)
+        torch.cuda.synchronize()
+        adt = (time.perf_counter() - t1) / reps
+        c = B.counters()
+        roof = None
+        if kernel == "wavefront":
+            roof = roofline_record(c, prec, kernel, scene, headline_shape)
+        elif kernel == "bounce":     # per-bounce launches are only bracketed on request (it slows the render): one extra, profiled render
+            B.render_device(*sc2, B.make_params(W, H, spp_total, depth, *counts2, flags=fl | B.FLAG_PROFILE, seed=seed, **tile),
+                            o2.data_ptr(), 0, stream.cuda_stream, prec)
+            torch.cuda.synchronize()
+            roof = roofline_record(B.counters(), prec, kernel, scene, headline_shape)
+            roof["note"] = "kernel time from a separate event-bracketed render (slower than the timed steps)"
+        del o2
+        return samples_per_step / adt / 1e6, adt * 1e3, roof
 
     result = None
     if rank == 0:
         assert bool(torch.isfinite(img).all()), "non-finite pixels"
-        # ---- roofline leg: one extra render with every bounce launch bracketed by HIP events
-        def roofline_leg(prec, out_t):
-            pp = B.make_params(W, H, spp_total, depth, ns, nm, nt, flags=kflag | B.POST_NONE | B.FLAG_PROFILE,
-                               seed=scenes.seed_for(3), **tile)
-            B.render_device(*sc, pp, out_t.data_ptr(), 0, stream.cuda_stream, prec)
-            torch.cuda.synchronize()
-            c = B.counters()
-            nbytes = algorithmic_bytes(c, 4 if prec == "f32" else 8)
-            launches = max(1, c["bounce_launches"])
-            avg_ms = c["bounce_kernel_ms"] / launches
-            achieved = nbytes / (c["bounce_kernel_ms"] * 1e-3) / 1e9 if c["bounce_kernel_ms"] > 0 else 0.0
-            traffic, tsrc = None, None
-            tfile = os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.scene, prec))
-            if os.path.exists(tfile) and (W, H, spp_total, depth, world) == (1920, 1080, 64, 8, 1):
-                tj = json.load(open(tfile))      # PMC bytes per k_bounce launch of this same command (profiles/run_profile.sh)
-                traffic, tsrc = round(tj["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(tfile)
-            return {"bound": "hbm", "kernel": "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
-                    "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(avg_ms, 5), "launches": launches,
-                    "bytes_per_sample": round(nbytes / c["samples"], 2), "segments_per_sample": round(c["segments"] / c["samples"], 4),
-                    "bounce_kernel_share": round(c["bounce_kernel_ms"] / max(c["kernel_ms"], 1e-9), 4)}
-
-        roof = roofline_leg(args.prec, out) if args.kernel == "wavefront" else None
+        if args.kernel == "wavefront":
+            roof = roofline_record(c_timed, args.prec, args.kernel, scene_name, headline_shape)
+        elif args.kernel == "bounce":
+            roof = side_run(scene_name, "bounce", args.prec, reps=1)[2]
+        else:
+            roof = None
         # ---- the same workload in the other precision (N=1 only; informational, never `value`)
         alt = None
         if world == 1 and not args.no_alt_precision:
             ap_ = "f32" if args.prec == "f64" else "f64"
-            out2 = torch.empty((3, rows, W), dtype=torch.float32 if ap_ == "f32" else torch.float64, device="cuda")
-            B.render_device(*sc, params, out2.data_ptr(), 0, stream.cuda_stream, ap_)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                B.render_device(*sc, params, out2.data_ptr(), 0, stream.cuda_stream, ap_)
-            torch.cuda.synchronize()
-            adt = (time.perf_counter() - t1) / 3
-            aroof = roofline_leg(ap_, out2) if args.kernel == "wavefront" else None
-            alt = {"dtype": ap_, "value": round(samples_per_step / adt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(adt * 1e3, 3),
-                   "roofline_frac": aroof and aroof["frac"], "achieved_GBps": aroof and aroof["achieved"],
-                   "bytes_per_sample": aroof and aroof["bytes_per_sample"]}
-            del out2
+            v, ms, aroof = side_run(scene_name, args.kernel, ap_)
+            alt = {"dtype": ap_, "value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": aroof}
+        # ---- stress scene and the other kernel organisations (N=1 only; informational)
+        stress, orgs = None, None
+        if world == 1 and not args.no_extras:
+            if scene_name != "s3" and args.config != "c5":
+                v, ms, sroof = side_run("s3", args.kernel, args.prec)
+                stress = {"scene": "s3", "what": "the same frame with the scene inside a closed box: every path runs all max_depth segments (SURVEY 8d)",
+                          "dtype": args.prec, "value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": sroof}
+            orgs = {}
+            for k in ("wavefront", "bounce", "mega"):
+                if k != args.kernel:
+                    v, ms, oroof = side_run(scene_name, k, args.prec)
+                    orgs[k] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "dtype": args.prec,
+                               "hbm_frac": oroof and oroof["frac"], "bytes_per_sample": oroof and oroof["bytes_per_sample"],
+                               "avg_launch_ms": oroof and oroof["avg_launch_ms"], "launches": oroof and oroof["launches"]}
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             import oracle_py as O
+            ns, nm, nt = counts
             cores = min(O.max_threads(), host_cpu_share())     # the box's cgroup CPU share, not the host's core count
-            O.render(*sc, O.make_params(W, H, 1, depth, ns, nm, nt, seed=scenes.seed_for(3), rows=8), "f64", n_threads=cores)   # spin up the threads
+            O.render(*sc, O.make_params(W, H, 1, depth, ns, nm, nt, seed=seed, rows=8), "f64", n_threads=cores)   # spin up the threads
+            cal_rows = H if nt <= 32 else 16                    # the oracle scans every triangle: calibrate a mesh scene on a few rows
+            r0 = (H - cal_rows) // 2
             t1 = time.perf_counter()
-            O.render(*sc, O.make_params(W, H, 2, depth, ns, nm, nt, seed=scenes.seed_for(3)), "f64", n_threads=cores)
+            O.render(*sc, O.make_params(W, H, 2, depth, ns, nm, nt, seed=seed, row0=r0, rows=cal_rows), "f64", n_threads=cores)
             cal = time.perf_counter() - t1
-            rate = 2 * W * H / max(cal, 1e-6)                    # samples/s from a whole-frame spp=2 calibration
-            cpu_spp = max(1, min(512, int(rate * args.cpu_seconds / (W * H))))   # short runs read fast: cap the sample
+            rate = 2 * W * cal_rows / max(cal, 1e-6)             # samples/s from the calibration
+            cpu_spp = max(1, min(512, int(rate * args.cpu_seconds / (W * cal_rows))))   # short runs read fast: cap the sample
             t1 = time.perf_counter()
-            O.render(*sc, O.make_params(W, H, cpu_spp, depth, ns, nm, nt, seed=scenes.seed_for(3)), "f64", n_threads=cores)
+            O.render(*sc, O.make_params(W, H, cpu_spp, depth, ns, nm, nt, seed=seed, row0=r0, rows=cal_rows), "f64", n_threads=cores)
             cdt = time.perf_counter() - t1
-            # the reference's own loop is serial (examples/julia-raytracer.jl:392): one thread, the middle 64 rows at spp 16
-            t1 = time.perf_counter()
-            O.render(*sc, O.make_params(W, H, 16, depth, ns, nm, nt, seed=scenes.seed_for(3), row0=H // 2 - 32, rows=64), "f64", n_threads=1)
-            sdt = time.perf_counter() - t1
-            cpu = {"value": round(W * H * cpu_spp / cdt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                   "sample": "%dx%d spp=%d depth=%d, same scene/seed, Float64 oracle (oracle/spira_oracle.c, OpenMP over rows), %.1f s"
-                             % (W, H, cpu_spp, depth, cdt),
-                   "single_thread_value": round(W * 64 * 16 / sdt / 1e6, 4),
-                   "single_thread_sample": "rows %d..%d of the same frame at spp=16, 1 thread, %.1f s" % (H // 2 - 32, H // 2 + 31, sdt)}
+            cpu = {"value": round(W * cal_rows * cpu_spp / cdt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                   "sample": "%dx%d (rows %d..%d) spp=%d depth=%d, same scene/seed, Float64 oracle (oracle/spira_oracle.c, OpenMP over rows), %.1f s"
+                             % (W, H, r0, r0 + cal_rows - 1, cpu_spp, depth, cdt)}
+            if nt <= 32:
+                # the reference's own loop is serial (examples/julia-raytracer.jl:392): one thread, the middle 64 rows at spp 16
+                t1 = time.perf_counter()
+                O.render(*sc, O.make_params(W, H, 16, depth, ns, nm, nt, seed=seed, row0=H // 2 - 32, rows=64), "f64", n_threads=1)
+                sdt = time.perf_counter() - t1
+                cpu["single_thread_value"] = round(W * 64 * 16 / sdt / 1e6, 4)
+                cpu["single_thread_sample"] = "rows %d..%d of the same frame at spp=16, 1 thread, %.1f s" % (H // 2 - 32, H // 2 + 31, sdt)
         result = {
             "metric": "Msamples/sec at 1920x1080 spp=64 depth=8; fraction of HBM roofline",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": args.prec, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %dx%d spp=%d depth=%d, scene %s (%s), semantics A, %s kernels, tile-sharded "
+            "config": {"workload": "%s: %dx%d spp=%d depth=%d, scene %s (%s), semantics A, %s kernel organisation, tile-sharded "
                                    "over %d GPU(s) in 8-row stripes + one RCCL gather" %
-                                   (W, H, spp_total, depth, args.scene,
-                                    {"s1": "create_scene() of src/spira-metal-optimized.jl", "s2": "create_scene() of examples/julia-raytracer.jl",
-                                     "s3": "S1 inside a closed box", "s4": "create_scene_with_obj() of examples/julia-raytracer.jl with an 81 920-triangle procedural mesh (BVH)"}[args.scene], args.kernel, world),
-                       "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": args.scene, "kernel": args.kernel,
+                                   (cfg["name"], W, H, spp_total, depth, scene_name, SCENE_DESC[scene_name], args.kernel, world),
+                       "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": scene_name, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
-            "roofline": roof, "cpu_baseline": cpu, "other_precision": alt,
+            "roofline": roof, "cpu_baseline": cpu, "other_precision": alt, "stress": stress, "organisations": orgs,
         }
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -77,8 +77,10 @@ extern "C" {
 #define SPIRA_SEM_METAL         0x00000002u  /* path_trace src/spira_path_trace_kernel.metal:140-269 */
 /* kernel organisation */
 #define SPIRA_KERNEL_MASK       0x000000F0u
-#define SPIRA_KERNEL_WAVEFRONT  0x00000000u  /* SoA ray queues + per-bounce kernels + compaction (default) */
+#define SPIRA_KERNEL_WAVEFRONT  0x00000000u  /* wavefront, default: SoA hit queues, ballot/popcount compaction, ONE persistent
+                                                launch per pass in which every wave walks all bounces on its own queue region */
 #define SPIRA_KERNEL_MEGA       0x00000010u  /* one thread walks one whole path in registers */
+#define SPIRA_KERNEL_BOUNCE     0x00000020u  /* wavefront as in round 1: SoA RAY queues, one launch per bounce (comparison point) */
 /* display transform applied to out_img (out_hdr is always the linear mean) */
 #define SPIRA_POST_MASK         0x00000F00u
 #define SPIRA_POST_ACES         0x00000000u  /* clamp(aces(x),0,1)        examples/julia-raytracer.jl:370-384 */
@@ -90,8 +92,9 @@ extern "C" {
 #define SPIRA_ROWS_BOTTOM_UP    0x00001000u  /* row 0 = v=0 (bottom), the device-buffer order of :1177-1188 */
 
 /* diagnostics */
-#define SPIRA_FLAG_PROFILE      0x00010000u  /* bracket every bounce launch with HIP events (fills
-                                                spira_counters.bounce_kernel_ms; slows the render) */
+#define SPIRA_FLAG_PROFILE      0x00010000u  /* SPIRA_KERNEL_BOUNCE: bracket every bounce launch with HIP events (slows the
+                                                render).  The default organisation always brackets its one launch per pass, so
+                                                spira_counters.bounce_kernel_ms is filled by every wavefront render. */
 
 /* ---- limits ---- */
 #define SPIRA_MAX_DEPTH        255u        /* bounce index is packed into 8 bits of the RNG key */

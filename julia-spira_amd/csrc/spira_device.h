@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
         for (uint32_t w = 0; w < WPB; ++w) n_blk += a.cnt_in[blockIdx.x * WPB + w];
         n_mine = a.cnt_in[wid];
         if (n_blk == 0) {                           // block-uniform: nothing left in this workgroup's regions
-            if (lane == 0) { if (scatter) a.cnt_out[wid] = 0; a.blk_stats[4 * wid] = 0; a.blk_stats[4 * wid + 1] = 0; a.blk_stats[4 * wid + 2] = 0; }
+            if (lane == 0) { if (scatter) a.cnt_out[wid] = 0; a.blk_stats[4 * wid] = 0; a.blk_stats[4 * wid + 1] = 0; a.blk_stats[4 * wid + 2] = 0; a.blk_stats[4 * wid + 3] = 0; }
             return;
         }
     }
@@ -704,6 +704,237 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
         a.blk_stats[4 * wid] = n_seg;
         a.blk_stats[4 * wid + 1] = n_rmw;
         a.blk_stats[4 * wid + 2] = n_store;
+        a.blk_stats[4 * wid + 3] = FIRST ? 0u : n_seg;          // rays read from a queue == rays written to one
+    }
+}
+
+// ====================================================================== the persistent wave-autonomous path kernel
+// One launch per pass.  Differences from k_bounce (kept as SPIRA_KERNEL_BOUNCE, the round-1 organisation):
+//   * the queues hold HITS, not rays: the intersection of segment k+1 runs at the END of stage k, right after the new
+//     direction is known, so a ray that leaves the scene adds its sky term and never touches memory; what is queued is
+//     {hit point, incoming direction, throughput, path index, hit reference}.  Every lane that enters the shading code of a
+//     stage holds a hit (in k_bounce the later bounces ran their shading at ~50 % lane utilisation behind the hit/miss
+//     branch), and on an open scene fewer than half as many packets go through HBM;
+//   * a wave never waits for any other wave: it owns its region of both queues, so it simply carries on with the next
+//     stage on what it has just written — all max_depth stages in one launch, the survivor count in a register, no count
+//     arrays, no per-bounce launches and launch tails; the scene is staged into LDS once per workgroup per pass.
+// Stage 0 generates camera rays (sub-chunks dealt round-robin over the waves) and intersects them; stage k >= 1 reads the
+// hits of segment k.  Each stage: (1) shade the hit — emitted radiance, throughput, what the scatter needs — and put the
+// RNG keys on the wave's LDS work list; (2) drain the list cooperatively (random_in_unit_sphere); (3) new direction, closest
+// hit of the next segment, sky term on a miss, ballot/popcount compaction of the hits into the wave's region.
+// The arithmetic per segment is the same statements in the same order as k_bounce / k_mega, so results are bit-identical.
+template <class T> struct PathArgs {
+    SceneGlobal<T> scene;
+    RenderConst<T> rc;
+    RayQueue<T> q[2];                // stage k writes q[k & 1] and (k >= 1) reads q[(k + 1) & 1]
+    uint32_t *qref[2];               // Float32 only: the hit reference of each queued packet (Float64 packs it beside q)
+    Pack3<T> *L;                     // per-path radiance of the pass batch (slot-major)
+    uint32_t *blk_stats;             // [NW][4] segments, radiance RMWs, radiance stores, packets enqueued
+    uint32_t cap;                    // region size in packets (a multiple of R*64)
+    uint32_t pass;
+    uint32_t n_first;                // number of paths in this pass
+};
+
+// queue word C.y: the path index (bit 31 = "L[q] already holds radiance") and, in Float64, the hit reference beside it
+__device__ __forceinline__ float pack_qref(uint32_t q, uint32_t, float) { return __uint_as_float(q); }
+__device__ __forceinline__ double pack_qref(uint32_t q, uint32_t ref, double) { return __longlong_as_double((long long)((unsigned long long)q | ((unsigned long long)ref << 32))); }
+__device__ __forceinline__ uint32_t unpack_q(float w) { return __float_as_uint(w); }
+__device__ __forceinline__ uint32_t unpack_q(double w) { return (uint32_t)(unsigned long long)__double_as_longlong(w); }
+__device__ __forceinline__ uint32_t unpack_ref(double w) { return (uint32_t)((unsigned long long)__double_as_longlong(w) >> 32); }
+
+template <class T, int R, bool BVH>
+__global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const PathArgs<T> a) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
+    constexpr bool kRefArray = sizeof(T) == 4;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t NW = gridDim.x * WPB, wid = blockIdx.x * WPB + wave;
+    const RenderConst<T> &rc = a.rc;
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // the only workgroup barrier of the kernel
+    Pack4<T> *s_rnd = reinterpret_cast<Pack4<T> *>(lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles)) + wave * SUB;
+    const uint32_t region = wid * a.cap;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t ref_base = sc.n_spheres + sc.n_triangles;     // references >= ref_base are BVH triangle slots
+    uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0;
+    uint32_t n_in = 0;                                           // packets waiting in this wave's region (stages >= 1)
+    const uint32_t n_sub_first = (a.n_first + SUB - 1) / SUB;
+
+    for (uint32_t stage = 0; stage < rc.max_depth; ++stage) {
+        const bool first = stage == 0;
+        const bool scatter = stage + 1 < rc.max_depth;
+        const RayQueue<T> qin = a.q[(stage + 1) & 1], qout = a.q[stage & 1];
+        const uint32_t *rin = a.qref[(stage + 1) & 1];
+        uint32_t *rout = a.qref[stage & 1];
+        const uint32_t limit = first ? a.n_first : n_in;
+        const uint32_t n_sub = first ? n_sub_first : (n_in + SUB - 1) / SUB;
+        uint32_t fill = 0;
+        for (uint32_t sub = first ? wid : 0u; sub < n_sub; sub += first ? NW : 1u) {
+            Vec<T> o[R], beta[R];
+            Pending<T> pend[R];
+            uint32_t q[R], ent[R];
+            uint32_t n_list = 0;
+            // ---------------- phase 1: the hit of segment `stage`
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const uint32_t idx = sub * SUB + r * 64 + lane;
+                pend[r].kind = kDead;
+                bool want = false;
+                RngKey key;
+                if (idx < limit) {
+                    uint32_t pixel, sample, pi, pj;
+                    Vec<T> d;
+                    int prim; uint32_t slot = 0;
+                    if (first) {
+                        q[r] = idx;
+                        path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
+                        camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
+                        beta[r] = mk<T>(1, 1, 1);
+                        T t;
+                        prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot);      // :335
+                        ++n_seg;
+                        if (prim >= 0) o[r] = o[r] + d * t;                              // point_at, :138 / :183
+                    } else {
+                        const Pack4<T> A = qin.A[region + idx], B = qin.B[region + idx];
+                        const Pack2<T> C = qin.C[region + idx];
+                        o[r] = mk<T>(A.x, A.y, A.z);                                     // the hit point
+                        d = mk<T>(A.w, B.x, B.y);
+                        beta[r] = mk<T>(B.z, B.w, C.x);
+                        q[r] = unpack_q(C.y);
+                        uint32_t ref;
+                        if constexpr (kRefArray) ref = rin[region + idx]; else ref = unpack_ref(C.y);
+                        prim = (int)ref;
+                        if (BVH && ref >= ref_base) { prim = (int)ref_base; slot = ref - ref_base; }
+                    }
+                    const uint32_t qi = q[r] & 0x7FFFFFFFu;
+                    const bool has_l = (q[r] >> 31) != 0;        // only ever set in stages >= 1
+                    if (prim < 0) {                              // (stage 0) the camera ray leaves the scene: sky, :365-366
+                        const Vec<T> c = sky_term<T>(d, beta[r]);
+                        Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
+                        a.L[qi] = l;
+                        ++n_store;
+                    } else {
+                        Vec<T> contrib;
+                        const bool has_contrib = shade_hit<T, BVH>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r]);
+                        // Path radiance L[q]: while bit 31 of q is clear a term is a plain store (0 + x == x exactly); the
+                        // load -> add -> store round trip only remains for paths that met an emitter earlier.
+                        if (has_contrib) {
+                            Pack3<T> l; l.x = contrib.x; l.y = contrib.y; l.z = contrib.z;
+                            if (has_l) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + contrib.x; l.y = l0.y + contrib.y; l.z = l0.z + contrib.z; ++n_rmw; }
+                            else ++n_store;
+                            a.L[qi] = l;
+                            q[r] |= 0x80000000u;
+                        } else if (!scatter && !has_l) {          // the path ends here without ever having contributed
+                            Pack3<T> l; l.x = 0; l.y = 0; l.z = 0;
+                            a.L[qi] = l;
+                            ++n_store;
+                        }
+                        want = (pend[r].kind == kDiffuse || pend[r].kind == kSpecRough);
+                        if (want) {
+                            if (!first) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
+                            key = rng_key(rc.sA, rc.sB, pixel, sample, stage);
+                        }
+                    }
+                }
+                if (scatter) {
+                    const unsigned long long m = __ballot(want);
+                    if (want) {                                   // append to the wave's work list
+                        ent[r] = n_list + __popcll(m & lt_mask);
+                        uint32_t *kw = reinterpret_cast<uint32_t *>(&s_rnd[ent[r]]);
+                        kw[0] = key.hA; kw[1] = key.hB;
+                    }
+                    n_list += (uint32_t)__popcll(m);
+                }
+            }
+            if (!scatter) continue;        // uniform: the last stage only collects emitted radiance
+            wave_lds_sync();
+            // ---------------- phase 2: cooperative random_in_unit_sphere() over the wave's work list
+            {
+                uint32_t e = lane, t = 1, next = 64;
+                bool have = e < n_list;
+                RngKey k; k.hA = 0; k.hB = 0; k.hBr = 0;
+                if (have) {
+                    const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
+                    k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
+                }
+                while (__any(have)) {
+                    bool done = false;
+                    if (have) {
+                        T u0, u1, u2;
+                        rng3<T>(k, t, u0, u1, u2, (T)(1.0 / 1048576.0));
+                        Vec<T> c = mk<T>(u0, u1, u2) - mk<T>(1, 1, 1);                   // :311
+                        done = dot(c, c) < (T)1.0;                                      // :312
+                        if (!done && t == kMaxTries) { c = mk<T>(0, 0, 0); done = true; }
+                        if (done) { Pack4<T> w; w.x = c.x; w.y = c.y; w.z = c.z; w.w = 0; s_rnd[e] = w; }
+                        ++t;
+                    }
+                    const unsigned long long m = __ballot(done);
+                    if (done) {                                   // take the next unclaimed entry
+                        e = next + __popcll(m & lt_mask); t = 1;
+                        have = e < n_list;
+                        if (have) {
+                            const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
+                            k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
+                        }
+                    }
+                    next += (uint32_t)__popcll(m);
+                }
+            }
+            wave_lds_sync();
+            // ---------------- phase 3: direction, closest hit of segment stage+1, compaction of the hits
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bool hit = false;
+                Vec<T> nd = mk<T>(0, 0, 0);
+                uint32_t ref = 0;
+                if (pend[r].kind != kDead) {
+                    Vec<T> rnd = mk<T>(0, 0, 0);
+                    if (pend[r].kind != kMirror) { const Pack4<T> w = s_rnd[ent[r]]; rnd = mk<T>(w.x, w.y, w.z); }
+                    nd = segment_back<T>(o[r], pend[r], rnd);
+                    T t; uint32_t slot;
+                    const int prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot);   // :335 of the next level
+                    ++n_seg;
+                    if (prim < 0) {                               // the path leaves the scene: its last term, :365-366
+                        const Vec<T> c = sky_term<T>(nd, beta[r]);
+                        const uint32_t qi = q[r] & 0x7FFFFFFFu;
+                        Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
+                        if (q[r] >> 31) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + c.x; l.y = l0.y + c.y; l.z = l0.z + c.z; ++n_rmw; }
+                        else ++n_store;
+                        a.L[qi] = l;
+                    } else {
+                        hit = true;
+                        o[r] = o[r] + nd * t;                     // point_at, :138 / :183
+                        ref = (BVH && prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim;
+                    }
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const uint32_t dst = region + fill + __popcll(m & lt_mask);
+                    Pack4<T> A, B; Pack2<T> C;
+                    A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = nd.x;
+                    B.x = nd.y; B.y = nd.z; B.z = beta[r].x; B.w = beta[r].y;
+                    C.x = beta[r].z; C.y = pack_qref(q[r], ref, (T)0);
+                    qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
+                    if constexpr (kRefArray) rout[dst] = ref;
+                }
+                fill += (uint32_t)__popcll(m);
+            }
+            wave_lds_sync();      // the list slots are rewritten by the next sub-chunk's phase 1
+        }
+        if (!scatter) break;
+        n_in = fill;
+        n_enq += fill;
+        if (n_in == 0) break;              // wave-uniform: every path of this wave has ended
+        // The wave now reads what its own lanes have just written: on one CU (one vector L1, one L2) a workgroup-scope
+        // release/acquire (wait for the stores) is all that takes.  No other wave ever touches this region.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) { n_rmw += __shfl_down(n_rmw, sft); n_seg += __shfl_down(n_seg, sft); n_store += __shfl_down(n_store, sft); }
+    if (lane == 0) {
+        a.blk_stats[4 * wid] = n_seg;
+        a.blk_stats[4 * wid + 1] = n_rmw;
+        a.blk_stats[4 * wid + 2] = n_store;
+        a.blk_stats[4 * wid + 3] = n_enq;          // wave-uniform
     }
 }
 
@@ -1029,10 +1260,11 @@ __global__ __launch_bounds__(64) void k_trace_variant(const BounceArgs<T> a, con
 
 // Per-pass resolve: accum[pix] += L[slot][pix] for slot = 0..k_eff-1, in sample order — the
 // `color = color + ray_color(...)` of examples/julia-raytracer.jl:401 in the same order.
-// Workgroup 0 also folds the pass's per-workgroup statistics [n_bounce][G][2] into the render totals.
+// Workgroup 0 also folds the pass's per-wave statistics (n_rows x {segments, radiance RMWs, radiance stores, rays
+// enqueued}) into the render totals.
 template <class T>
 __global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack3<T> *L, uint32_t tile_pixels, uint32_t k_eff, int first_pass,
-                                                    const uint32_t *blk_stats, uint32_t n_bounce, uint32_t G, Stats *stats) {
+                                                    const uint32_t *blk_stats, uint32_t n_rows, Stats *stats) {
     for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < tile_pixels; p += gridDim.x * kBlock) {
         Pack4<T> acc;
         if (first_pass) { acc.x = 0; acc.y = 0; acc.z = 0; acc.w = 0; } else acc = accum[p];
@@ -1057,12 +1289,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(Pack4<T> *accum, const Pack3
         if (threadIdx.x < 4) red[threadIdx.x] = 0;
         __syncthreads();
         unsigned long long seg = 0, enq = 0, rmw = 0, sto = 0;
-        for (uint32_t i = threadIdx.x; i < n_bounce * G; i += kBlock) {
-            const unsigned long long n = blk_stats[4 * i];
-            seg += n;
-            if (i >= G) enq += n;                 // rays read from a queue == rays written to one
+        for (uint32_t i = threadIdx.x; i < n_rows; i += kBlock) {
+            seg += blk_stats[4 * i];
             rmw += blk_stats[4 * i + 1];
             sto += blk_stats[4 * i + 2];
+            enq += blk_stats[4 * i + 3];
         }
         for (int sft = 32; sft > 0; sft >>= 1) { seg += __shfl_down(seg, sft); enq += __shfl_down(enq, sft); rmw += __shfl_down(rmw, sft); sto += __shfl_down(sto, sft); }
         if ((threadIdx.x & 63) == 0) { atomicAdd(&red[0], seg); atomicAdd(&red[1], enq); atomicAdd(&red[2], rmw); atomicAdd(&red[3], sto); }

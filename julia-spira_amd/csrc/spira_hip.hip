@@ -66,7 +66,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf qA[2], qB[2], qC[2], qR[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
     SceneStore scene;                         // the scene of the current call (host-array entry points)
     spira::Stats *h_stats = nullptr;          // pinned
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -171,7 +171,7 @@ int validate_params(const void *camera12, const spira_params *p, uint32_t nt, ui
     if (sem != SPIRA_SEM_A && sem != SPIRA_SEM_CPU && sem != SPIRA_SEM_METAL) return fail(SPIRA_E_UNSUPPORTED, "unknown integrator semantics");
     if (sem != SPIRA_SEM_A && nt) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_CPU / SPIRA_SEM_METAL are sphere-only, like their sources");
     uint32_t kern = p->flags & SPIRA_KERNEL_MASK;
-    if (kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
+    if (kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA && kern != SPIRA_KERNEL_BOUNCE) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
     uint32_t rows = p->rows;
     if (rows == 0) rows = p->height;
     else if (p->stripe_count > 1) {
@@ -291,6 +291,13 @@ void launch_bounce(int R, dim3 grid, size_t lds, hipStream_t st, const spira::Bo
     else launch_bounce_r<T, FIRST, false>(R, grid, lds, st, a);
 }
 
+template <class T>
+void launch_path(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<T> &a) {
+    const bool bvh = a.scene.n_bvh_tris != 0;
+    if (R == 2) { if (bvh) launch_lds(spira::k_path<T, 2, true>, grid, dim3(spira::kBlock), lds, st, a); else launch_lds(spira::k_path<T, 2, false>, grid, dim3(spira::kBlock), lds, st, a); }
+    else        { if (bvh) launch_lds(spira::k_path<T, 1, true>, grid, dim3(spira::kBlock), lds, st, a); else launch_lds(spira::k_path<T, 1, false>, grid, dim3(spira::kBlock), lds, st, a); }
+}
+
 int profile_events(Ctx &c, size_t need) {
     while (c.ev_pool.size() < need) {
         hipEvent_t e;
@@ -365,7 +372,9 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     const uint32_t sem = p->flags & SPIRA_SEM_MASK;
     // the secondary variants run one lane per path / per pixel: no queues, no bounce kernels
     const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA || sem != SPIRA_SEM_A;
-    const bool profile = (p->flags & SPIRA_FLAG_PROFILE) != 0 && !mega;
+    const bool per_bounce = !mega && (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_BOUNCE;     // round-1 organisation: one launch per bounce
+    const bool persistent = !mega && !per_bounce;                                                // k_path: one launch per pass
+    const bool profile = ((p->flags & SPIRA_FLAG_PROFILE) != 0 && per_bounce) || persistent;     // k_path launches are always bracketed (2 events per pass)
     int R = (int)env_u32("SPIRA_R", 2);
     if (R != 1 && R != 2) R = 2;
 
@@ -392,6 +401,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
             if (int rc = c.qA[i].ensure(q_rays * sizeof(P4))) return rc;
             if (int rc = c.qB[i].ensure(q_rays * sizeof(P4))) return rc;
             if (int rc = c.qC[i].ensure(q_rays * sizeof(P2))) return rc;
+            if (persistent && sizeof(T) == 4) { if (int rc = c.qR[i].ensure(q_rays * sizeof(uint32_t))) return rc; }
         }
     if (int rc = c.L.ensure(batch * sizeof(spira::Pack3<T>))) return rc;
     if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
@@ -421,7 +431,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
 
     size_t n_prof = 0;
     if (profile) {
-        n_prof = (size_t)n_pass * std::max<uint32_t>(p->max_depth, 1) * 2;
+        n_prof = (size_t)n_pass * (persistent ? 1 : std::max<uint32_t>(p->max_depth, 1)) * 2;
         if (int rc = profile_events(c, n_prof)) return rc;
     }
     c.ev_used = 0;
@@ -463,7 +473,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
             const uint32_t n_first = (uint32_t)((uint64_t)k_eff * tile_pixels);
             a.pass = pass;
             a.n_first = n_first;
-            uint32_t G = 0;
+            uint32_t G = 0, stat_rows = 0;
             if (sem == SPIRA_SEM_CPU) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
                 launch_lds(spira::k_variant_cpu<T>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
@@ -473,8 +483,25 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 if (a.scene.n_bvh_tris) launch_lds(spira::k_mega<T, true>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 else launch_lds(spira::k_mega<T, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
                 ++launches;
+            } else if (persistent) {
+                // one launch: every wave walks all max_depth stages on its own region of the hit queues
+                spira::PathArgs<T> pa{};
+                pa.scene = a.scene; pa.rc = a.rc; pa.L = a.L; pa.pass = pass; pa.n_first = n_first;
+                geometry(n_first, G, pa.cap);
+                stat_rows = G * wpb;
+                for (int i = 0; i < 2; ++i) {
+                    pa.q[i] = {(P4 *)c.qA[i].p, (P4 *)c.qB[i].p, (P2 *)c.qC[i].p};
+                    pa.qref[i] = (uint32_t *)c.qR[i].p;
+                }
+                pa.blk_stats = (uint32_t *)c.blkstats.p;
+                const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4);       // + one work list per wave
+                HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
+                launch_path<T>(R, dim3(G), lds_b, st, pa);
+                HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
+                ++launches;
             } else {
                 geometry(n_first, G, a.cap);
+                stat_rows = p->max_depth * G * wpb;
                 const size_t nw = (size_t)G * wpb;
                 for (uint32_t b = 0; b < p->max_depth; ++b) {
                     a.bounce = b;
@@ -495,7 +522,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
             uint32_t rblocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
             hipLaunchKernelGGL((spira::k_resolve<T>), dim3(rblocks), dim3(spira::kBlock), 0, st, (P4 *)c.accum.p, (const spira::Pack3<T> *)c.L.p,
                                (uint32_t)tile_pixels, k_eff, (pass == 0 && !progressive) ? 1 : 0, mega ? (const uint32_t *)nullptr : (const uint32_t *)c.blkstats.p,
-                               p->max_depth, G * wpb, (spira::Stats *)c.stats.p);
+                               stat_rows, (spira::Stats *)c.stats.p);
             ++launches;
         }
     }
@@ -519,7 +546,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     c.last.samples = (uint64_t)p->spp * tile_pixels;
     c.last.passes = p->max_depth ? n_pass : 0;
     c.last.launches = launches;
-    c.last.bounce_launches = (mega || !p->max_depth) ? 0 : (uint64_t)n_pass * p->max_depth;
+    c.last.bounce_launches = (mega || !p->max_depth) ? 0 : (uint64_t)n_pass * (persistent ? 1 : p->max_depth);
     c.last_valid = true;
     c.last_pending = true;
     c.last_stream = st;
@@ -691,7 +718,7 @@ void spira_shutdown(void) {
         if (!c.init) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
-        for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); }
+        for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); }
         c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.." || exit 1
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision $*"
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-precision --no-extras $*"
 pmc() { local name=$1; shift
     rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -o pmc -- python3 $BENCH > "$OUT/pmc_$name.log" 2>&1
     echo "pmc $name rc=$?"; }

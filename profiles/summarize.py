@@ -34,11 +34,11 @@ def main():
                 continue
             lines.append("| %s | %s | %.3f | %.2f | %s | %.2f | %.2f |" % (short(r["Name"]), r["Calls"], int(r["TotalDurationNs"]) / 1e6,
                                                                            float(r["AverageNs"]) / 1e3, r["Percentage"], int(r["MinNs"]) / 1e3, int(r["MaxNs"]) / 1e3))
-            if "k_bounce" in r["Name"]:
+            if "k_bounce" in r["Name"] or "k_path" in r["Name"]:
                 tot_b += int(r["TotalDurationNs"])
                 cnt_b += int(r["Calls"])
         if cnt_b:
-            lines += ["", "k_bounce (all instantiations): %d launches, average %.2f us" % (cnt_b, tot_b / cnt_b / 1e3), ""]
+            lines += ["", "dominant kernel (k_path / k_bounce, all instantiations): %d launches, average %.2f us" % (cnt_b, tot_b / cnt_b / 1e3), ""]
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
     dur = defaultdict(float)
@@ -75,6 +75,10 @@ def main():
             lines.append("- VALU lane utilisation SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) = %.3f" %
                          (c.get("SQ_THREAD_CYCLES_VALU", 0) / max(1.0, 64 * c["SQ_ACTIVE_INST_VALU"])))
             lines.append("- VALU instructions per wave = %.1f" % (c["SQ_INSTS_VALU"] / max(1.0, c["SQ_WAVES"])))
+        if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+            # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs; SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)
+            lines.append("- VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = %.3f" %
+                         (c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8)))
         if "SQ_WAIT_ANY" in c and "SQ_ACTIVE_INST_ANY" in c:
             tot = c["SQ_WAIT_ANY"] + c["SQ_WAIT_INST_ANY"] + c["SQ_ACTIVE_INST_ANY"]
             lines.append("- wave-cycle shares: WAIT_ANY %.2f, WAIT_INST_ANY %.2f, ACTIVE_INST_ANY %.2f" %
@@ -82,18 +86,30 @@ def main():
         if "TCC_HIT_sum" in c:
             lines.append("- L2 hit rate = %.3f" % (c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
         lines.append("")
-    # machine-readable PMC traffic of the dominant kernel (all k_bounce instantiations), per launch,
-    # for bench.py's roofline.traffic field
-    rd = sum(agg[k].get("FETCH_SIZE", 0) for k in agg if k.startswith("k_bounce")) * 1024
-    wr = sum(agg[k].get("WRITE_SIZE", 0) for k in agg if k.startswith("k_bounce")) * 1024
-    nl = sum(calls[k].get("FETCH_SIZE", 0) for k in agg if k.startswith("k_bounce"))
-    if nl:
+    # machine-readable PMC figures of the dominant kernel (k_path, or all k_bounce instantiations), per launch, for bench.py's
+    # roofline.traffic / roofline.valu fields
+    for dom in ("k_path", "k_bounce"):
+        ks = [k for k in agg if k.startswith(dom)]
+        nl = sum(calls[k].get("FETCH_SIZE", 0) for k in ks)
+        if not nl:
+            continue
         import json
-        json.dump({"kernel": "k_bounce", "launches": nl, "fetch_bytes_raw": rd, "fetch_bytes_x2": 2 * rd, "write_bytes": wr,
-                   "hbm_bytes_per_launch": (2 * rd + wr) / nl,
-                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); FETCH_SIZE doubled per "
-                             "MI355X_MICROARCH.md HBM section (gfx950 reports half of a 16 B/lane streaming read)",
-                   "source": os.path.basename(src.rstrip("/"))}, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
+        tot = lambda name: sum(agg[k].get(name, 0) for k in ks)
+        rd, wr = tot("FETCH_SIZE") * 1024, tot("WRITE_SIZE") * 1024
+        out = {"kernel": dom, "launches": nl, "fetch_bytes_raw": rd, "fetch_bytes_x2": 2 * rd, "write_bytes": wr,
+               "hbm_bytes_per_launch": (2 * rd + wr) / nl,
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); FETCH_SIZE doubled per "
+                         "MI355X_MICROARCH.md HBM section (gfx950 reports half of a 16 B/lane streaming read)",
+               "source": os.path.basename(src.rstrip("/"))}
+        if tot("SQ_ACTIVE_INST_VALU") and tot("GRBM_GUI_ACTIVE"):
+            w = tot("SQ_WAIT_ANY") + tot("SQ_WAIT_INST_ANY") + tot("SQ_ACTIVE_INST_ANY")
+            out["valu"] = {"busy_frac": round(tot("SQ_ACTIVE_INST_VALU") * 4 / (1024 * tot("GRBM_GUI_ACTIVE") / 8), 4),
+                           "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / max(1.0, 64 * tot("SQ_ACTIVE_INST_VALU")), 4),
+                           "valu_insts_per_launch": tot("SQ_INSTS_VALU") / max(1, sum(calls[k].get("SQ_INSTS_VALU", 0) for k in ks)),
+                           "wave_cycle_shares": {"wait_any": round(tot("SQ_WAIT_ANY") / w, 3), "wait_inst_any": round(tot("SQ_WAIT_INST_ANY") / w, 3),
+                                                 "active_inst_any": round(tot("SQ_ACTIVE_INST_ANY") / w, 3)} if w else None}
+        json.dump(out, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
+        break
     open(dst, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

@@ -42,7 +42,7 @@ def test_fuzz_against_oracle(gpu, oracle):
         sem = 0
         if nt == 0 and rng.random() < 0.3:
             sem = int(rng.choice([1, 2]))
-        kflag = gpu.KERNEL_MEGA if rng.random() < 0.3 else gpu.KERNEL_WAVEFRONT
+        kflag = (gpu.KERNEL_WAVEFRONT, gpu.KERNEL_WAVEFRONT, gpu.KERNEL_BOUNCE, gpu.KERNEL_MEGA)[int(rng.integers(0, 4))]
         seed = int(rng.integers(0, 2 ** 40))
         batch = int(rng.choice([0, 1, W * H * 2 + 3, 1 << 20]))
         tile = {}

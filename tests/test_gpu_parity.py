@@ -158,8 +158,26 @@ def test_max_depth_zero_is_black(gpu):
 def test_mega_equals_wavefront_bitwise(gpu, prec):
     s = scenes.scene_s2()
     a, _ = gpu.render(*_args(s), gpu.make_params(200, 120, 6, 6, 5, 6, 1, flags=gpu.KERNEL_WAVEFRONT, seed=8), prec)
+    seg = gpu.counters()["segments"]
     b, _ = gpu.render(*_args(s), gpu.make_params(200, 120, 6, 6, 5, 6, 1, flags=gpu.KERNEL_MEGA, seed=8), prec)
-    assert np.array_equal(a, b)
+    assert np.array_equal(a, b) and gpu.counters()["segments"] == seg
+    c, _ = gpu.render(*_args(s), gpu.make_params(200, 120, 6, 6, 5, 6, 1, flags=gpu.KERNEL_BOUNCE, seed=8), prec)     # round-1 organisation
+    assert np.array_equal(a, c) and gpu.counters()["segments"] == seg
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("scene_name", ["s1", "s3", "s4"])
+def test_three_kernel_organisations_agree_bitwise(gpu, prec, scene_name):
+    """persistent hit-queue kernel (default) == per-bounce ray queues (round 1) == megakernel, pixel for pixel and segment for
+    segment, over max_depth 1..9, odd sizes, several passes (batch_rays) and R = 1 / 2 rays per lane."""
+    s = {"s1": scenes.scene_s1, "s3": scenes.scene_s3, "s4": lambda: scenes.scene_s4(level=3)}[scene_name]()
+    ns, nm, nt = _counts(s)
+    for (W, H, spp, depth, batch) in [(97, 61, 5, 1, 0), (97, 61, 5, 2, 0), (160, 90, 7, 3, 20000), (131, 77, 9, 9, 0), (64, 36, 33, 6, 5000)]:
+        ref, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.KERNEL_MEGA, seed=17), prec)
+        seg = gpu.counters()["segments"]
+        for k in (gpu.KERNEL_WAVEFRONT, gpu.KERNEL_BOUNCE):
+            got, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=k, seed=17, batch_rays=batch), prec)
+            assert np.array_equal(ref, got) and gpu.counters()["segments"] == seg, (W, H, spp, depth, batch, k)
 
 
 def test_batch_size_does_not_change_results(gpu):
