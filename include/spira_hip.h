@@ -179,6 +179,22 @@ int spira_render_device_f64(const double *spheres5, const double *materials8, co
                             const double camera12[12], const spira_params *params,
                             double *d_out_hdr, double *d_out_img, void *stream);
 
+/* ---- multi-device render on ONE node ----
+ * Replaces the backend branch of render (src/spira-metal-optimized.jl:1460-1479) for a host that owns several GPUs: the
+ * frame is dealt to devices 0..n_devices-1 as interleaved 8-row stripes (spira_params "Tiling"; the RNG is keyed by the
+ * global pixel, so the result is bit-identical to a one-device render), each device renders its tile on its own stream
+ * driven by its own host thread inside the library, no collective runs while rendering, and ONE RCCL exchange (grouped
+ * ncclSend / ncclRecv = a gather; n-1 point-to-point transfers over xGMI that arrive at device 0 at once) brings the tiles
+ * to device 0, which permutes the rows back to image order and copies the frame to the caller's HOST buffers.
+ * params->rows / stripe_* must be 0.  librccl.so.1 is opened at run time (the copy the process already carries, if any);
+ * SPIRA_E_UNSUPPORTED when none can be found.  spira_get_counters afterwards reports device 0's tile. */
+int spira_render_multi_f32(const float *spheres5, const float *materials8, const float *triangles10,
+                           const float camera12[12], const spira_params *params, int n_devices,
+                           float *out_hdr, float *out_img);
+int spira_render_multi_f64(const double *spheres5, const double *materials8, const double *triangles10,
+                           const double camera12[12], const spira_params *params, int n_devices,
+                           double *out_hdr, double *out_img);
+
 /* ---- scene handles: validate, build (BVH) and upload a scene ONCE, render it many times ----
  * Replaces the per-render uploads `sphere_data_gpu = MtlArray(sphere_data)` / `material_data_gpu = ...` of
  * render_hybrid_gpu (src/spira-metal-optimized.jl:1247-1254) after prepare_scene_data (:515-542): the host-array

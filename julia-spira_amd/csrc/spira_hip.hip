@@ -7,6 +7,8 @@
 // kernel, fully asynchronous on one HIP stream, the live-ray counts staying on the device (one
 // word per wave), and a pass carries `slots` samples of every pixel of the tile at once.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl is opened at run time (dlopen), never linked
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -16,6 +18,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spira_hip.h"
@@ -67,6 +70,7 @@ struct Ctx {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     DevBuf qA[2], qB[2], qC[2], qR[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
     SceneStore scene;                         // the scene of the current call (host-array entry points)
     spira::Stats *h_stats = nullptr;          // pinned
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -379,7 +383,9 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     if (R != 1 && R != 2) R = 2;
 
     // ---- launch geometry: NW = 4*G autonomous waves per bounce kernel, each owning `cap` rays of both queues
-    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", 16);
+    // workgroups per CU: the persistent kernel runs a whole pass per launch, so its launch tail is one workgroup's share of the
+    // pass: 32 per CU (8 rounds of resident workgroups) measured best on S1 (16: -3.5 %, 64: -1 %, 128: -5 %; S3 likes 64-128, +1.7 %)
+    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", persistent ? 32 : 16);
     const uint32_t wpb = spira::kBlock / 64;
     const uint32_t sub = 64 * R;                                   // rays per wave sub-chunk
     auto geometry = [&](uint64_t n_first, uint32_t &G, uint32_t &cap) {
@@ -659,6 +665,188 @@ int scene_create(const T *spheres5, const T *materials8, const T *triangles10, u
     return 0;
 }
 
+
+// ======================================================================= multi-device render (one node)
+// RCCL is opened at run time: libspira_hip.so has no link-time dependency on it, and when the host process already
+// carries an RCCL (PyTorch does) that copy is the one found.
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    int n = 0;                           // communicators currently held (devices 0..n-1)
+    ncclComm_t comms[kMaxDevices] = {};
+    std::mutex mu;
+};
+Rccl g_rccl;
+
+int rccl_load(Rccl &r) {
+    if (r.handle) return 0;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return fail(SPIRA_E_UNSUPPORTED, std::string("RCCL not found (dlopen librccl.so.1): ") + dlerror());
+#define SPIRA_RCCL_SYM(field, sym)                                                        \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, #sym));                \
+    if (!r.field) { r.handle = nullptr; return fail(SPIRA_E_UNSUPPORTED, "RCCL symbol missing: " #sym); }
+    SPIRA_RCCL_SYM(CommInitAll, ncclCommInitAll)
+    SPIRA_RCCL_SYM(CommDestroy, ncclCommDestroy)
+    SPIRA_RCCL_SYM(GroupStart, ncclGroupStart)
+    SPIRA_RCCL_SYM(GroupEnd, ncclGroupEnd)
+    SPIRA_RCCL_SYM(Send, ncclSend)
+    SPIRA_RCCL_SYM(Recv, ncclRecv)
+    SPIRA_RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef SPIRA_RCCL_SYM
+    return 0;
+}
+
+void rccl_release(Rccl &r) {
+    for (int i = 0; i < r.n; ++i) if (r.comms[i]) { (void)r.CommDestroy(r.comms[i]); r.comms[i] = nullptr; }
+    r.n = 0;
+}
+
+int rccl_comms(Rccl &r, int n) {          // communicators for devices 0..n-1 (ncclCommInitAll once per n)
+    if (int rc = rccl_load(r)) return rc;
+    if (r.n == n) return 0;
+    rccl_release(r);
+    int devs[kMaxDevices];
+    for (int i = 0; i < n; ++i) devs[i] = i;
+    ncclResult_t e = r.CommInitAll(r.comms, n, devs);
+    if (e != ncclSuccess) return fail(SPIRA_E_HIP, std::string("ncclCommInitAll: ") + r.GetErrorString(e));
+    r.n = n;
+    return 0;
+}
+
+// Row permutation of the gathered tiles back to image order, for both outputs at once.
+//   stack: [n][2][3][max_rows][W] (tile of rank r: hdr planes, then img planes; rows in the rank's local order)
+//   full : [2][3][H][W]
+// Global row y belongs to rank (y / stripe_h) % n, local row ((y / stripe_h) / n) * stripe_h + y % stripe_h (spira_params "Tiling").
+template <class T>
+__global__ void k_assemble(const T *stack, T *full, uint32_t n, uint32_t stripe_h, uint32_t max_rows, uint32_t W, uint32_t H) {
+    const size_t total = (size_t)6 * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t x = (uint32_t)(i % W);
+        const uint32_t y = (uint32_t)((i / W) % H);
+        const uint32_t pl = (uint32_t)(i / ((size_t)W * H));            // 0..5: output * 3 + channel
+        const uint32_t sq = y / stripe_h, r = sq % n, lr = (sq / n) * stripe_h + y % stripe_h;
+        full[i] = stack[(((size_t)r * 6 + pl) * max_rows + lr) * W + x];
+    }
+}
+
+constexpr uint32_t kMultiStripeH = 8;
+
+template <class T>
+int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p, int n_devices,
+                      T *out_hdr, T *out_img) {
+    if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
+    if (p->rows != 0 || p->stripe_count != 0) return fail(SPIRA_E_INVALID, "spira_render_multi tiles the frame itself: rows / stripe_* must be 0");
+    const int avail = spira_device_count();
+    // SPIRA_MULTI_REHEARSE=1 (a one-GPU box): all ranks render on device 0 one after the other and their tiles reach the stack by
+    // device copies instead of RCCL — exercises tiling, re-pitching and reassembly for any n; not a measurement
+    const bool rehearse = env_u32("SPIRA_MULTI_REHEARSE", 0) != 0;
+    if (n_devices < 1 || n_devices > kMaxDevices || (!rehearse && n_devices > avail)) return fail(SPIRA_E_INVALID, "n_devices out of range (1 .. spira_device_count())");
+    if (avail < 1) return fail(SPIRA_E_NO_DEVICE, "no HIP device");
+    // validate once on the calling thread, so that argument errors are reported before any thread or communicator exists
+    {
+        uint32_t rows = 0;
+        const uint32_t nt = triangles10 ? p->n_triangles : 0;
+        if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, nt)) return rc;
+        if (int rc = validate_params(camera12, p, nt, &rows)) return rc;
+    }
+    const uint32_t n = (uint32_t)n_devices, W = p->width, H = p->height;
+    if (stripe_rows(H, kMultiStripeH, n, n - 1) == 0) return fail(SPIRA_E_INVALID, "image has fewer 8-row stripes than devices");
+    const uint32_t max_rows = stripe_rows(H, kMultiStripeH, n, 0);
+    const size_t tile_elems = (size_t)6 * max_rows * W;                 // hdr planes + img planes, padded to the largest tile
+    std::lock_guard<std::mutex> rl(g_rccl.mu);                           // one multi-device render at a time
+    if (!rehearse) { if (int rc = rccl_comms(g_rccl, n_devices)) return rc; }
+
+    std::vector<int> rcs(n, 0);
+    std::vector<std::string> errs(n);
+    const int caller_device = tl_device;
+    auto worker = [&](uint32_t r) {
+        tl_device = rehearse ? 0 : (int)r;
+        auto bail = [&](int rc) { rcs[r] = rc; errs[r] = tl_err; };
+        Ctx *cp = nullptr;
+        if (int rc = get_ctx(&cp)) return bail(rc);
+        Ctx &c = *cp;
+        hipStream_t st = c.stream;
+        {
+            std::lock_guard<std::mutex> lock(c.mu);
+            if (int rc = c.multi_tile.ensure(2 * tile_elems * sizeof(T))) return bail(rc);      // the tile + a scratch copy for ragged tiles
+            if (r == 0 || rehearse) {
+                if (int rc = c.multi_stack.ensure((size_t)n * tile_elems * sizeof(T))) return bail(rc);
+                if (int rc = c.multi_full.ensure((size_t)6 * H * W * sizeof(T))) return bail(rc);
+            }
+        }
+        spira_params tp = *p;
+        tp.rows = stripe_rows(H, kMultiStripeH, n, r);
+        tp.row0 = 0; tp.stripe_h = kMultiStripeH; tp.stripe_count = n; tp.stripe_rank = r;
+        if (n == 1) { tp.rows = 0; tp.stripe_h = 0; tp.stripe_count = 0; tp.stripe_rank = 0; }
+        T *d_hdr = (T *)c.multi_tile.p, *d_img = d_hdr + (size_t)3 * max_rows * W;
+        // render_impl writes each output as [3][rows][W] contiguously; the gather wants every tile at the pitch of the largest one
+        // ([6][max_rows][W]).  A tile with fewer rows (ragged last stripes) is rendered into the second half of the buffer and its
+        // six planes are re-pitched with one strided device copy.
+        const uint32_t rows_r = (n == 1) ? H : tp.rows;
+        if (rows_r != max_rows) {
+            T *scratch = d_hdr + tile_elems;
+            if (int rc = render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, scratch, scratch + (size_t)3 * rows_r * W, true, st)) return bail(rc);
+            hipError_t e = hipMemcpy2DAsync(d_hdr, (size_t)max_rows * W * sizeof(T), scratch, (size_t)rows_r * W * sizeof(T), (size_t)rows_r * W * sizeof(T), 6,
+                                            hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) { tl_err = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e); return bail(SPIRA_E_HIP); }
+        } else if (int rc = render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, d_hdr, d_img, true, st)) return bail(rc);
+        // ---- the one exchange of the path: every tile to device 0 (RCCL point-to-point over xGMI; n-1 transfers arrive at once)
+        if (rehearse) {
+            hipError_t he = hipMemcpyAsync((T *)c.multi_stack.p + (size_t)r * tile_elems, c.multi_tile.p, tile_elems * sizeof(T), hipMemcpyDeviceToDevice, st);
+            if (he != hipSuccess) { tl_err = std::string("hipMemcpyAsync: ") + hipGetErrorString(he); return bail(SPIRA_E_HIP); }
+            if (r + 1 < n) return;                 // the last rank assembles
+        } else {
+        const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat32 : ncclFloat64;
+        ncclResult_t e = g_rccl.GroupStart();
+        if (e == ncclSuccess) e = g_rccl.Send(c.multi_tile.p, tile_elems, dt, 0, g_rccl.comms[r], st);
+        if (e == ncclSuccess && r == 0)
+            for (uint32_t src = 0; src < n && e == ncclSuccess; ++src)
+                e = g_rccl.Recv((T *)c.multi_stack.p + (size_t)src * tile_elems, tile_elems, dt, (int)src, g_rccl.comms[0], st);
+        ncclResult_t e2 = g_rccl.GroupEnd();
+        if (e == ncclSuccess) e = e2;
+        if (e != ncclSuccess) { tl_err = std::string("RCCL gather: ") + g_rccl.GetErrorString(e); return bail(SPIRA_E_HIP); }
+        }
+        if (rehearse || r == 0) {
+            const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)6 * H * W + 255) / 256, (size_t)c.num_cus * 16);
+            hipLaunchKernelGGL((k_assemble<T>), dim3(blocks), dim3(256), 0, st, (const T *)c.multi_stack.p, (T *)c.multi_full.p, n, kMultiStripeH, max_rows, W, H);
+            const size_t plane3 = (size_t)3 * H * W * sizeof(T);
+            hipError_t he = hipSuccess;
+            if (out_hdr) he = hipMemcpyAsync(out_hdr, c.multi_full.p, plane3, hipMemcpyDeviceToHost, st);
+            if (he == hipSuccess && out_img) he = hipMemcpyAsync(out_img, (char *)c.multi_full.p + plane3, plane3, hipMemcpyDeviceToHost, st);
+            if (he != hipSuccess) { tl_err = std::string("hipMemcpyAsync: ") + hipGetErrorString(he); return bail(SPIRA_E_HIP); }
+        }
+        {
+            std::lock_guard<std::mutex> lock(c.mu);
+            if (int rc = mark_done(c, st)) return bail(rc);
+        }
+        hipError_t he = hipStreamSynchronize(st);
+        if (he != hipSuccess) { tl_err = std::string("hipStreamSynchronize: ") + hipGetErrorString(he); return bail(SPIRA_E_HIP); }
+    };
+    if (rehearse) {
+        for (uint32_t r = 0; r < n && !rcs[r ? r - 1 : 0]; ++r) worker(r);
+    } else {
+        std::vector<std::thread> threads;
+        for (uint32_t r = 1; r < n; ++r) threads.emplace_back(worker, r);
+        worker(0);                                    // device 0 on the calling thread
+        for (auto &t : threads) t.join();
+    }
+    tl_device = caller_device;
+    (void)hipSetDevice(caller_device);
+    for (uint32_t r = 0; r < n; ++r)
+        if (rcs[r]) return fail(rcs[r], "device " + std::to_string(r) + ": " + errs[r]);
+    return 0;
+}
+
 }  // namespace
 
 // ======================================================================= C ABI
@@ -712,6 +900,7 @@ int spira_get_counters(spira_counters *out) {
 }
 
 void spira_shutdown(void) {
+    { std::lock_guard<std::mutex> rl(g_rccl.mu); if (g_rccl.handle) rccl_release(g_rccl); }
     for (int d = 0; d < kMaxDevices; ++d) {
         Ctx &c = g_ctx[d];
         std::lock_guard<std::mutex> lock(c.mu);
@@ -719,7 +908,7 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); }
-        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release();
+        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
         (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop); (void)hipEventDestroy(c.ev_done);
@@ -812,6 +1001,16 @@ int spira_render_scene_device_f32(const spira_scene *scene, const float cam[12],
 int spira_render_scene_device_f64(const spira_scene *scene, const double cam[12], const spira_params *p, double *d_hdr, double *d_img, void *stream) {
     if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
     return render_impl<double>(scene, nullptr, nullptr, nullptr, cam, p, d_hdr, d_img, true, stream);
+}
+
+// ---- multi-device render on one node: interleaved 8-row stripes, one host thread + stream per device, one RCCL gather
+int spira_render_multi_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, int n_devices,
+                           float *out_hdr, float *out_img) {
+    return render_multi_impl<float>(s, m, t, cam, p, n_devices, out_hdr, out_img);
+}
+int spira_render_multi_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, int n_devices,
+                           double *out_hdr, double *out_img) {
+    return render_multi_impl<double>(s, m, t, cam, p, n_devices, out_hdr, out_img);
 }
 
 int spira_trace_paths_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t n_paths,

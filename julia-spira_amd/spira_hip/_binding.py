@@ -28,6 +28,7 @@ EXPORTS = [
     "spira_tonemap_f32", "spira_stripe_rows", "spira_accumulate_f32", "spira_accumulate_f64", "spira_accumulate_device_f32",
     "spira_accumulate_device_f64", "spira_scene_create_f32", "spira_scene_create_f64", "spira_scene_destroy",
     "spira_render_scene_f32", "spira_render_scene_f64", "spira_render_scene_device_f32", "spira_render_scene_device_f64",
+    "spira_render_multi_f32", "spira_render_multi_f64",
 ]
 
 
@@ -163,6 +164,21 @@ def render_device(spheres5, materials8, triangles10, camera12, params, d_hdr_ptr
     fn = lib().spira_render_device_f32 if prec == "f32" else lib().spira_render_device_f64
     _check(fn(sp, mp, tp, cp, C.byref(params), C.c_void_p(d_hdr_ptr or None), C.c_void_p(d_img_ptr or None),
               C.c_void_p(stream_ptr or None)))
+
+
+def render_multi(spheres5, materials8, triangles10, camera12, params, n_devices, prec="f32", want_hdr=True, want_img=False):
+    """spira_render_multi_*: the frame on n_devices GPUs of this node (stripes + one RCCL gather to device 0), host outputs."""
+    npdt, _ = _dt(prec)
+    s, sp = _arr(spheres5, npdt)
+    m, mp = _arr(materials8, npdt)
+    t, tp = _arr(triangles10, npdt)
+    c, cp = _arr(camera12, npdt)
+    hdr = np.empty((3, params.height, params.width), dtype=npdt) if want_hdr else None
+    img = np.empty((3, params.height, params.width), dtype=npdt) if want_img else None
+    fn = lib().spira_render_multi_f32 if prec == "f32" else lib().spira_render_multi_f64
+    _check(fn(sp, mp, tp, cp, C.byref(params), C.c_int(n_devices), hdr.ctypes.data_as(C.c_void_p) if want_hdr else None,
+              img.ctypes.data_as(C.c_void_p) if want_img else None))
+    return hdr, img
 
 
 class Scene:
