@@ -81,6 +81,9 @@ extern "C" {
                                                 launch per pass in which every wave walks all bounces on its own queue region */
 #define SPIRA_KERNEL_MEGA       0x00000010u  /* one thread walks one whole path in registers */
 #define SPIRA_KERNEL_BOUNCE     0x00000020u  /* wavefront as in round 1: SoA RAY queues, one launch per bounce (comparison point) */
+/* The organisation applies to SPIRA_SEM_A and, for WAVEFRONT vs the rest, to SPIRA_SEM_METAL (wavefront: every wave owns a block of
+ * pixels and walks sample after sample on it, the LCG state travelling in the hit packet; MEGA / BOUNCE: one lane per pixel walks
+ * all its samples).  SPIRA_SEM_CPU always runs one lane per path. */
 /* display transform applied to out_img (out_hdr is always the linear mean) */
 #define SPIRA_POST_MASK         0x00000F00u
 #define SPIRA_POST_ACES         0x00000000u  /* clamp(aces(x),0,1)        examples/julia-raytracer.jl:370-384 */

@@ -1099,87 +1099,125 @@ template <class T> __device__ __forceinline__ void sincos_turn(T r, T &sn, T &cs
     }
 }
 
-// One sample of path_trace, src/spira_path_trace_kernel.metal:140-269 (x, y = gid, 0-based, y = 0 is v = 0).
+// ---- the pieces of path_trace, src/spira_path_trace_kernel.metal:140-269, shared by the one-lane-per-pixel kernel
+// (k_variant_metal) and the wavefront kernel (k_path_metal)
+// Closest sphere, intersect_sphere :109-136 + the selection loop :181-189 (`t < closest_t`: ties keep the EARLIER sphere).
 template <class T>
-__device__ __forceinline__ uint32_t path_metal(const SceneLds<T> &sc, const RenderConst<T> &rc, uint32_t x, uint32_t y, uint32_t &st,
-                                               Vec<T> &acc, int *rec_prims, T *rec_ts, T *rec_dirs) {
+__device__ __forceinline__ int metal_intersect(const SceneLds<T> &sc, const Vec<T> o, const Vec<T> d, T &closest) {
     const T EPSILON = (T)0.0001f, INF_ = (T)1e20f;                                  // :6-7
+    closest = INF_;
+    int hit = -1;
+    const T a = dot(d, d);
+    for (uint32_t s = 0; s < sc.n_spheres; ++s) {
+        const Pack4<T> c = sc.sph[s];
+        Vec<T> oc = o - mk<T>(c.x, c.y, c.z);
+        T half_b = dot(oc, d);
+        T cc = dot(oc, oc) - c.w;
+        T disc = half_b * half_b - a * cc;                                          // :117
+        T t = INF_;
+        if (disc > (T)0.0) {
+            T sq = sqrt_rn(disc);
+            T root = (-half_b - sq) / a;                                            // :120
+            if (!(root > EPSILON)) root = (-half_b + sq) / a;                       // :127
+            if (root > EPSILON) t = root;                                           // :123 / :130
+        }
+        if (t < closest) { closest = t; hit = (int)s; }                             // :184-188
+    }
+    return hit;
+}
+
+// sky term of a miss, :192-198
+template <class T> __device__ __forceinline__ Vec<T> metal_sky(const Vec<T> d, const Vec<T> thr) {
+    T ts = (T)0.5 * (d.y + (T)1.0);
+    return mulv(thr, mk<T>(1, 1, 1) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts);
+}
+
+// Everything that follows a hit, :200-247: normal (the winning sphere's `normalize(hit_point - center)`, :123/:130 — the same
+// expression on the same values as the reference's per-candidate normal), flip towards the ray, emitted term, scatter (LCG draws
+// in the reference's order), throughput, Russian roulette after depth 3, throughput cut-off.  o/d: in = the segment's ray and
+// (o) its hit point, out = the scattered ray.  Returns whether the path goes on; `emitted` is thr_in * emission.
+template <class T>
+__device__ __forceinline__ bool metal_shade(const SceneLds<T> &sc, int hit, uint32_t depth, uint32_t &st, Vec<T> &o, Vec<T> &d, Vec<T> &thr,
+                                            Vec<T> &emitted, bool &has_emission) {
+    const T EPSILON = (T)0.0001f;
+    const Pack4<T> c = sc.sph[hit];
+    const Vec<T> hit_point = o;                                                     // :203 (computed by the caller: o + d * closest)
+    Vec<T> n = normalize(hit_point - mk<T>(c.x, c.y, c.z));
+    const int mi = sc.smat[hit];
+    const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
+    if (dot(d, n) > (T)0.0) n = mk<T>(-n.x, -n.y, -n.z);                            // :207-209
+    emitted = mulv(thr, mk<T>(mb.x, mb.y, mb.z));                                   // :212
+    has_emission = (mb.x != 0 || mb.y != 0 || mb.z != 0);
+    Vec<T> scatter_origin = hit_point + n * EPSILON;                                // :215
+    Vec<T> nd;
+    T xi = lcg_uniform(st, (T)0);
+    if (xi < ma.w) {                                                                // metal, :219
+        nd = d - n * ((T)2.0 * dot(d, n));                                          // reflect, :220
+        if (mb.w > (T)0.0) {                                                        // :221
+            Vec<T> pv = mk<T>(0, 0, 0);
+            for (int guard = 0; guard < 4096; ++guard) {                            // random_unit_vector, :61-70 (bounded: every wave must finish)
+                T a0 = lcg_uniform(st, (T)0), a1 = lcg_uniform(st, (T)0), a2 = lcg_uniform(st, (T)0);
+                pv = mk<T>(a0 * (T)2.0 - (T)1.0, a1 * (T)2.0 - (T)1.0, a2 * (T)2.0 - (T)1.0);
+                if (dot(pv, pv) < (T)1.0) break;
+            }
+            nd = normalize(nd + normalize(pv) * mb.w);                              // :222
+        }
+    } else {                                                                        // cosine hemisphere, :73-93
+        T r1 = lcg_uniform(st, (T)0), r2 = lcg_uniform(st, (T)0), sn, cs;
+        sincos_turn<T>(r1, sn, cs);
+        T sr = sqrt_rn(r2);
+        T hx = cs * sr, hy = sn * sr;
+        T zz = (T)1.0 - hx * hx - hy * hy;
+        T hz = sqrt_rn(zz > (T)0.0 ? zz : (T)0.0);
+        Vec<T> helper = abs_t(n.x) > (T)0.1 ? mk<T>(0, 1, 0) : mk<T>(1, 0, 0);      // :89
+        Vec<T> ua = normalize(cross(helper, n));
+        Vec<T> va = cross(n, ua);
+        nd = normalize((ua * hx + va * hy) + n * hz);                               // :93
+    }
+    o = scatter_origin; d = nd;
+    thr = mulv(thr, mk<T>(ma.x, ma.y, ma.z));                                       // :232
+    if (depth > 3) {                                                                // :236-243
+        T pc = thr.x > thr.y ? thr.x : thr.y; pc = pc > thr.z ? pc : thr.z;
+        pc = pc < (T)0.95f ? pc : (T)0.95f;
+        xi = lcg_uniform(st, (T)0);
+        if (xi > pc) return false;
+        thr = thr / pc;
+    }
+    { T mx = thr.x > thr.y ? thr.x : thr.y; mx = mx > thr.z ? mx : thr.z; if (mx < (T)0.01f) return false; }   // :246
+    return true;
+}
+
+// camera ray of a sample, :158-170 (x, y = gid, 0-based, y = 0 is v = 0)
+template <class T>
+__device__ __forceinline__ void metal_camera_ray(const RenderConst<T> &rc, uint32_t x, uint32_t y, uint32_t &st, Vec<T> &o, Vec<T> &d) {
     T xi = lcg_uniform(st, (T)0);
     T u_j = ((T)x + xi) / (T)rc.width;                                              // :161
     xi = lcg_uniform(st, (T)0);
     T v_j = ((T)y + xi) / (T)rc.height;                                             // :162
-    Vec<T> o = rc.cam_origin;
-    Vec<T> d = normalize(((rc.cam_llc + rc.cam_hor * u_j) + rc.cam_ver * v_j) - o); // :167-170
+    o = rc.cam_origin;
+    d = normalize(((rc.cam_llc + rc.cam_hor * u_j) + rc.cam_ver * v_j) - o);        // :167-170
+}
+
+// One sample of path_trace, one lane walking the whole path.
+template <class T>
+__device__ __forceinline__ uint32_t path_metal(const SceneLds<T> &sc, const RenderConst<T> &rc, uint32_t x, uint32_t y, uint32_t &st,
+                                               Vec<T> &acc, int *rec_prims, T *rec_ts, T *rec_dirs) {
+    Vec<T> o, d;
+    metal_camera_ray<T>(rc, x, y, st, o, d);
     Vec<T> thr = mk<T>(1, 1, 1);
     acc = mk<T>(0, 0, 0);
     uint32_t nseg = 0;
     for (uint32_t depth = 0; depth < rc.max_depth; ++depth) {                       // :176
         ++nseg;
-        T closest = INF_; int hit = -1; Vec<T> n = mk<T>(0, 0, 0);
-        for (uint32_t s = 0; s < sc.n_spheres; ++s) {                               // intersect_sphere, :109-136
-            const Pack4<T> c = sc.sph[s];
-            Vec<T> ctr = mk<T>(c.x, c.y, c.z);
-            Vec<T> oc = o - ctr;
-            T a = dot(d, d);
-            T half_b = dot(oc, d);
-            T cc = dot(oc, oc) - c.w;
-            T disc = half_b * half_b - a * cc;                                      // :117
-            T t = INF_; Vec<T> nn = mk<T>(0, 0, 0);
-            if (disc > (T)0.0) {
-                T sq = sqrt_rn(disc);
-                T root = (-half_b - sq) / a;                                        // :120
-                if (!(root > EPSILON)) root = (-half_b + sq) / a;                   // :127
-                if (root > EPSILON) { t = root; nn = normalize((o + d * t) - ctr); }   // :123 / :130
-            }
-            if (t < closest) { closest = t; hit = (int)s; n = nn; }                 // :184-188
-        }
+        T closest;
+        const int hit = metal_intersect<T>(sc, o, d, closest);
         if (rec_prims) { rec_prims[depth] = hit; rec_ts[depth] = hit >= 0 ? closest : (T)0; rec_dirs[3 * depth] = d.x; rec_dirs[3 * depth + 1] = d.y; rec_dirs[3 * depth + 2] = d.z; }
-        if (hit == -1) {                                                            // :192-198
-            T ts = (T)0.5 * (d.y + (T)1.0);
-            acc = acc + mulv(thr, mk<T>(1, 1, 1) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts);
-            break;
-        }
-        const int mi = sc.smat[hit];
-        const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
-        Vec<T> hit_point = o + d * closest;                                         // :203
-        if (dot(d, n) > (T)0.0) n = mk<T>(-n.x, -n.y, -n.z);                        // :207-209
-        acc = acc + mulv(thr, mk<T>(mb.x, mb.y, mb.z));                             // :212
-        Vec<T> scatter_origin = hit_point + n * EPSILON;                            // :215
-        Vec<T> nd;
-        xi = lcg_uniform(st, (T)0);
-        if (xi < ma.w) {                                                            // metal, :219
-            nd = d - n * ((T)2.0 * dot(d, n));                                      // reflect, :220
-            if (mb.w > (T)0.0) {                                                    // :221
-                Vec<T> pv = mk<T>(0, 0, 0);
-                for (int guard = 0; guard < 4096; ++guard) {                        // random_unit_vector, :61-70 (bounded: every wave must finish)
-                    T a0 = lcg_uniform(st, (T)0), a1 = lcg_uniform(st, (T)0), a2 = lcg_uniform(st, (T)0);
-                    pv = mk<T>(a0 * (T)2.0 - (T)1.0, a1 * (T)2.0 - (T)1.0, a2 * (T)2.0 - (T)1.0);
-                    if (dot(pv, pv) < (T)1.0) break;
-                }
-                nd = normalize(nd + normalize(pv) * mb.w);                          // :222
-            }
-        } else {                                                                    // cosine hemisphere, :73-93
-            T r1 = lcg_uniform(st, (T)0), r2 = lcg_uniform(st, (T)0), sn, cs;
-            sincos_turn<T>(r1, sn, cs);
-            T sr = sqrt_rn(r2);
-            T hx = cs * sr, hy = sn * sr;
-            T zz = (T)1.0 - hx * hx - hy * hy;
-            T hz = sqrt_rn(zz > (T)0.0 ? zz : (T)0.0);
-            Vec<T> helper = abs_t(n.x) > (T)0.1 ? mk<T>(0, 1, 0) : mk<T>(1, 0, 0);  // :89
-            Vec<T> ua = normalize(cross(helper, n));
-            Vec<T> va = cross(n, ua);
-            nd = normalize((ua * hx + va * hy) + n * hz);                           // :93
-        }
-        o = scatter_origin; d = nd;
-        thr = mulv(thr, mk<T>(ma.x, ma.y, ma.z));                                   // :232
-        if (depth > 3) {                                                            // :236-243
-            T pc = thr.x > thr.y ? thr.x : thr.y; pc = pc > thr.z ? pc : thr.z;
-            pc = pc < (T)0.95f ? pc : (T)0.95f;
-            xi = lcg_uniform(st, (T)0);
-            if (xi > pc) break;
-            thr = thr / pc;
-        }
-        { T mx = thr.x > thr.y ? thr.x : thr.y; mx = mx > thr.z ? mx : thr.z; if (mx < (T)0.01f) break; }   // :246
+        if (hit == -1) { acc = acc + metal_sky<T>(d, thr); break; }                 // :192-198
+        o = o + d * closest;                                                        // hit_point, :203
+        Vec<T> emitted; bool has_e;
+        const bool go_on = metal_shade<T>(sc, hit, depth, st, o, d, thr, emitted, has_e);
+        acc = acc + emitted;                                                        // :212
+        if (!go_on) break;
     }
     return nseg;
 }
@@ -1232,6 +1270,159 @@ __global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a,
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
     if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
+}
+
+// SEM 2 in wavefront form (k_path's organisation applied to the .metal estimator).  The estimator's LCG state runs from sample
+// to sample of a pixel (.metal :155/:268), so only ONE sample per pixel can be in flight: the parallelism is the tile's pixels,
+// not pixels x spp.  Every wave owns a fixed block of pixels (and the matching region of both hit queues) and walks, for each
+// sample in turn, all stages on it: stage 0 draws the jitter and intersects the camera ray, stage k shades the hits of depth k
+// (normal flip, emitted term, metal / cosine-hemisphere scatter, Russian roulette after depth 3, throughput cut-off — the LCG
+// state travels in the packet), intersects the scattered ray and compacts the hits by ballot + popcount.  A path that ends
+// adds its radiance to the pixel's running sum (`output_hdr_image[p] += L`, :264) and parks the LCG state for the next sample.
+// Same statements in the same order as k_variant_metal: bit-identical sums and states.
+template <class T> struct MetalArgs {
+    SceneGlobal<T> scene;
+    RenderConst<T> rc;
+    RayQueue<T> q[2];
+    uint2 *qx[2];                    // per packet: {hit sphere, LCG state}
+    Pack3<T> *L;                     // [tile_pixels] radiance of the pixel's sample in flight (only for paths that met an emitter)
+    Pack4<T> *accum;                 // [tile_pixels] running sums
+    uint32_t *rng_states;            // [tile_pixels]
+    uint32_t *blk_stats;             // [NW][4]
+    uint32_t ppw;                    // pixels per wave (a multiple of 64) == region size
+    int resume;                      // bit 0: continue the sums in accum, bit 1: continue the LCG states in rng_states
+};
+
+template <class T, int R>
+__global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(const MetalArgs<T> a) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t wid = blockIdx.x * WPB + wave;
+    const RenderConst<T> &rc = a.rc;
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    const uint32_t region = wid * a.ppw;                          // first pixel of this wave == first slot of its queue regions
+    const uint32_t n_pix = region < rc.tile_pixels ? (rc.tile_pixels - region < a.ppw ? rc.tile_pixels - region : a.ppw) : 0u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t n_seg = 0, n_enq = 0, n_rmw = 0, n_store = 0;
+    // initial sums / states of this wave's pixels
+    for (uint32_t i = lane; i < n_pix; i += 64) {
+        const uint32_t pl = region + i;
+        if (!(a.resume & 1)) { Pack4<T> z; z.x = 0; z.y = 0; z.z = 0; z.w = 0; a.accum[pl] = z; }
+        if (!(a.resume & 2)) {
+            uint32_t pixel, sample, pi, pj;
+            path_of<T>(rc, pl, 0, pi, pj, pixel, sample);
+            a.rng_states[pl] = metal_state0(rc.sA, rc.sB, pixel);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    // a path ends: pixel sum += the sample's radiance (last term `c`, on top of what L holds when the path met an emitter)
+    auto finish = [&](uint32_t pl, bool has_l, bool has_c, const Vec<T> c, uint32_t st) {
+        Vec<T> tot = mk<T>(0, 0, 0);
+        if (has_l) { const Pack3<T> l0 = a.L[pl]; tot = mk<T>(l0.x, l0.y, l0.z); if (has_c) tot = tot + c; ++n_rmw; }
+        else if (has_c) tot = c;
+        Pack4<T> sum = a.accum[pl];
+        sum.x = sum.x + tot.x; sum.y = sum.y + tot.y; sum.z = sum.z + tot.z;      // sum = sum + c, k_variant_metal's order
+        a.accum[pl] = sum;
+        a.rng_states[pl] = st;
+        ++n_store;
+    };
+
+    for (uint32_t s = 0; s < rc.spp; ++s) {
+        uint32_t n_in = 0;
+        for (uint32_t stage = 0; stage < rc.max_depth; ++stage) {
+            const bool first = stage == 0;
+            const RayQueue<T> qin = a.q[(stage + 1) & 1], qout = a.q[stage & 1];
+            const uint2 *xin = a.qx[(stage + 1) & 1];
+            uint2 *xout = a.qx[stage & 1];
+            const uint32_t limit = first ? n_pix : n_in;
+            uint32_t fill = 0;
+            for (uint32_t sub = 0; sub * SUB < limit; ++sub) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t idx = sub * SUB + r * 64 + lane;
+                    bool hit_next = false;
+                    Vec<T> o = mk<T>(0, 0, 0), d = mk<T>(0, 0, 0), thr = mk<T>(1, 1, 1);
+                    uint32_t q = 0, st = 0, ref = 0;
+                    if (idx < limit) {
+                        int hit;
+                        bool alive = true;
+                        if (first) {
+                            q = region + idx;
+                            uint32_t pixel, sample, pi, pj;
+                            path_of<T>(rc, q, 0, pi, pj, pixel, sample);
+                            st = a.rng_states[q];
+                            metal_camera_ray<T>(rc, pi - 1, pj - 1, st, o, d);
+                            T closest;
+                            hit = metal_intersect<T>(sc, o, d, closest);
+                            ++n_seg;
+                            if (hit < 0) { finish(q, false, true, metal_sky<T>(d, thr), st); alive = false; }
+                            else o = o + d * closest;                                   // hit_point, :203
+                        } else {
+                            const Pack4<T> A = qin.A[region + idx], B = qin.B[region + idx];
+                            const Pack2<T> C = qin.C[region + idx];
+                            const uint2 X = xin[region + idx];
+                            o = mk<T>(A.x, A.y, A.z); d = mk<T>(A.w, B.x, B.y); thr = mk<T>(B.z, B.w, C.x);
+                            q = Bits<T>::to_u32(C.y); hit = (int)X.x; st = X.y;
+                        }
+                        if (alive) {
+                            const uint32_t pl = q & 0x7FFFFFFFu;
+                            bool has_l = (q >> 31) != 0;
+                            Vec<T> emitted; bool has_e;
+                            const bool go_on = metal_shade<T>(sc, hit, stage, st, o, d, thr, emitted, has_e);
+                            if (go_on && stage + 1 < rc.max_depth) {
+                                if (has_e) {                                          // the path continues: park the emitted term in L
+                                    Pack3<T> l; l.x = emitted.x; l.y = emitted.y; l.z = emitted.z;
+                                    if (has_l) { const Pack3<T> l0 = a.L[pl]; l.x = l0.x + emitted.x; l.y = l0.y + emitted.y; l.z = l0.z + emitted.z; }
+                                    a.L[pl] = l;
+                                    has_l = true; q |= 0x80000000u;
+                                }
+                                T closest;
+                                const int nh = metal_intersect<T>(sc, o, d, closest);
+                                ++n_seg;
+                                if (nh < 0) finish(pl, has_l, true, metal_sky<T>(d, thr), st);
+                                else { hit_next = true; o = o + d * closest; ref = (uint32_t)nh; }
+                            } else finish(pl, has_l, has_e, emitted, st);              // Russian roulette, cut-off or max_depth
+                        }
+                    }
+                    const unsigned long long m = __ballot(hit_next);
+                    if (hit_next) {
+                        const uint32_t dst = region + fill + __popcll(m & lt_mask);
+                        Pack4<T> A, B; Pack2<T> C;
+                        A.x = o.x; A.y = o.y; A.z = o.z; A.w = d.x;
+                        B.x = d.y; B.y = d.z; B.z = thr.x; B.w = thr.y;
+                        C.x = thr.z; C.y = Bits<T>::from_u32(q);
+                        qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
+                        xout[dst] = make_uint2(ref, st);
+                    }
+                    fill += (uint32_t)__popcll(m);
+                }
+            }
+            n_in = fill;
+            n_enq += fill;
+            // the wave reads next what its own lanes have just written (queues, sums, LCG states): wait for the stores
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (n_in == 0) break;
+        }
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) { n_seg += __shfl_down(n_seg, sft); n_rmw += __shfl_down(n_rmw, sft); n_store += __shfl_down(n_store, sft); }
+    if (lane == 0) {
+        a.blk_stats[4 * wid] = n_seg;
+        a.blk_stats[4 * wid + 1] = n_rmw;
+        a.blk_stats[4 * wid + 2] = n_store;
+        a.blk_stats[4 * wid + 3] = n_enq;
+    }
+}
+
+// Folds per-wave statistics rows into the render totals (used after k_path_metal, which has no resolve pass).
+__global__ void k_fold_stats(const uint32_t *blk_stats, uint32_t n_rows, Stats *stats) {
+    unsigned long long seg = 0, enq = 0, rmw = 0, sto = 0;
+    for (uint32_t i = threadIdx.x; i < n_rows; i += blockDim.x) { seg += blk_stats[4 * i]; rmw += blk_stats[4 * i + 1]; sto += blk_stats[4 * i + 2]; enq += blk_stats[4 * i + 3]; }
+    for (int sft = 32; sft > 0; sft >>= 1) { seg += __shfl_down(seg, sft); enq += __shfl_down(enq, sft); rmw += __shfl_down(rmw, sft); sto += __shfl_down(sto, sft); }
+    if (threadIdx.x == 0) { stats->segments += seg; stats->rays_enqueued += enq; stats->radiance_rmw += rmw; stats->radiance_store += sto; }
 }
 
 // Diagnostic trace for the secondary variants (same outputs as k_trace).

@@ -69,7 +69,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], qR[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
     DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
     SceneStore scene;                         // the scene of the current call (host-array entry points)
     spira::Stats *h_stats = nullptr;          // pinned
@@ -376,6 +376,8 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     const uint32_t sem = p->flags & SPIRA_SEM_MASK;
     // the secondary variants run one lane per path / per pixel: no queues, no bounce kernels
     const bool mega = (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_MEGA || sem != SPIRA_SEM_A;
+    const bool metal_wavefront = sem == SPIRA_SEM_METAL && (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_WAVEFRONT;
+    uint64_t metal_launches = 0;
     const bool per_bounce = !mega && (p->flags & SPIRA_KERNEL_MASK) == SPIRA_KERNEL_BOUNCE;     // round-1 organisation: one launch per bounce
     const bool persistent = !mega && !per_bounce;                                                // k_path: one launch per pass
     const bool profile = ((p->flags & SPIRA_FLAG_PROFILE) != 0 && per_bounce) || persistent;     // k_path launches are always bracketed (2 events per pass)
@@ -466,6 +468,38 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
 
     if (p->max_depth == 0) {
         if (!progressive) HIP_TRY(hipMemsetAsync(c.accum.p, 0, tile_pixels * sizeof(P4), st));   // depth <= 0 -> Vec3(0,0,0), :330
+    } else if (sem == SPIRA_SEM_METAL && metal_wavefront) {
+        // the .metal estimator in wavefront form: every wave owns a block of pixels and walks sample after sample on it
+        spira::MetalArgs<T> ma{};
+        ma.scene = a.scene; ma.rc = a.rc;
+        const uint32_t g_res = (uint32_t)c.num_cus * (sizeof(T) == 8 ? SPIRA_WAVES_F64 : SPIRA_WAVES_F32);     // one resident round of workgroups
+        const uint64_t nw0 = (uint64_t)g_res * wpb;
+        ma.ppw = (uint32_t)((((tile_pixels + nw0 - 1) / nw0) + 63) / 64 * 64);
+        const uint32_t Gm = (uint32_t)((tile_pixels + (uint64_t)ma.ppw * wpb - 1) / ((uint64_t)ma.ppw * wpb));
+        const uint64_t slots_q = (uint64_t)Gm * wpb * ma.ppw;
+        for (int i = 0; i < 2; ++i) {
+            if (int rc = c.qA[i].ensure(slots_q * sizeof(P4))) return rc;
+            if (int rc = c.qB[i].ensure(slots_q * sizeof(P4))) return rc;
+            if (int rc = c.qC[i].ensure(slots_q * sizeof(P2))) return rc;
+            if (int rc = c.qX[i].ensure(slots_q * sizeof(uint2))) return rc;
+            ma.q[i] = {(P4 *)c.qA[i].p, (P4 *)c.qB[i].p, (P2 *)c.qC[i].p};
+            ma.qx[i] = (uint2 *)c.qX[i].p;
+        }
+        if (!d_rng) {
+            if (int rc = c.rng.ensure(tile_pixels * sizeof(uint32_t))) return rc;
+            d_rng = (uint32_t *)c.rng.p;
+        }
+        if (int rc = c.blkstats.ensure((size_t)Gm * wpb * 4 * sizeof(uint32_t))) return rc;
+        ma.L = (spira::Pack3<T> *)c.L.p; ma.accum = (P4 *)c.accum.p; ma.rng_states = d_rng; ma.blk_stats = (uint32_t *)c.blkstats.p;
+        ma.resume = progressive ? (sample0 > 0 ? 3 : 1) : 0;          // bit 0: continue the sums, bit 1: continue the LCG states
+        if (int rc = profile_events(c, 2)) return rc;
+        HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
+        if (R == 2) launch_lds(spira::k_path_metal<T, 2>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
+        else launch_lds(spira::k_path_metal<T, 1>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
+        HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
+        hipLaunchKernelGGL(spira::k_fold_stats, dim3(1), dim3(64), 0, st, (const uint32_t *)c.blkstats.p, Gm * wpb, (spira::Stats *)c.stats.p);
+        launches += 2;
+        metal_launches = 1;
     } else if (sem == SPIRA_SEM_METAL) {
         // one launch: every lane owns a pixel and walks its spp samples (the LCG state runs through them)
         uint32_t blocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
@@ -552,7 +586,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     c.last.samples = (uint64_t)p->spp * tile_pixels;
     c.last.passes = p->max_depth ? n_pass : 0;
     c.last.launches = launches;
-    c.last.bounce_launches = (mega || !p->max_depth) ? 0 : (uint64_t)n_pass * (persistent ? 1 : p->max_depth);
+    c.last.bounce_launches = metal_launches ? metal_launches : ((mega || !p->max_depth) ? 0 : (uint64_t)n_pass * (persistent ? 1 : p->max_depth));
     c.last_valid = true;
     c.last_pending = true;
     c.last_stream = st;
@@ -907,7 +941,7 @@ void spira_shutdown(void) {
         if (!c.init) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
-        for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); }
+        for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qX[i].release(); }
         c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
