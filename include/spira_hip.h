@@ -94,6 +94,18 @@ extern "C" {
  * (examples/julia-raytracer.jl:408) and img[height-j+1, i] (src/spira-metal-optimized.jl:1445) */
 #define SPIRA_ROWS_BOTTOM_UP    0x00001000u  /* row 0 = v=0 (bottom), the device-buffer order of :1177-1188 */
 
+/* extensions.  The reference only NAMES these features (README.md:10, a comment at
+ * src/spira_path_trace_kernel.metal:225): there is no reference code and so no parity to pin — the semantics below are the build's
+ * own, restated in oracle/ and compared GPU vs oracle like everything else, and never part of the graded SPIRA_SEM_A runs.
+ * SPIRA_SEM_A only; default (wavefront) and MEGA organisations. */
+#define SPIRA_EXT_DIELECTRIC    0x00020000u  /* a material whose roughness is NEGATIVE is a smooth dielectric of refractive index
+                                                -roughness, tinted by albedo: Snell refraction, Schlick reflectance, total internal
+                                                reflection; one uniform draw per interaction picks reflection or refraction */
+#define SPIRA_EXT_SPECTRAL      0x00040000u  /* hero-wavelength spectral transport: one wavelength per path (380..730 nm), RGB
+                                                reflectance / emission / sky uplifted with the SPD tables of include/spira_spd.h
+                                                (staged into LDS), radiance accumulated as linear sRGB through the wavelength's
+                                                colour-matching response */
+
 /* diagnostics */
 #define SPIRA_FLAG_PROFILE      0x00010000u  /* SPIRA_KERNEL_BOUNCE: bracket every bounce launch with HIP events (slows the
                                                 render).  The default organisation always brackets its one launch per pass, so

@@ -103,7 +103,11 @@ template <class T> struct SceneLds {
     const Pack4<T> *bvh_nodes;
     const Pack4<T> *bvh_tris;
     uint32_t n_bvh_tris;
+    const T *spd;           // SPIRA_EXT_SPECTRAL: kSpdRows x kSpdN table (include/spira_spd.h) staged behind the scene, else unused
 };
+
+constexpr int kSpdN = 36, kSpdRows = 6;      // include/spira_spd.h
+constexpr uint32_t kExtDielectric = 0x00020000u, kExtSpectral = 0x00040000u;   // SPIRA_EXT_* (include/spira_hip.h)
 
 template <class T> struct SceneGlobal {     // flat arrays exactly as passed through the C ABI
     const T *spheres5;      // prepare_scene_data, src/spira-metal-optimized.jl:515-529
@@ -113,11 +117,14 @@ template <class T> struct SceneGlobal {     // flat arrays exactly as passed thr
     const Pack4<T> *bvh_nodes;
     const Pack4<T> *bvh_tris;
     uint32_t n_bvh_tris;
+    const T *spd;           // device copy of the SPD table, or NULL (extension off)
 };
 
 template <class T> __host__ __device__ inline size_t scene_lds_bytes(uint32_t ns, uint32_t nm, uint32_t nt) {
     size_t b = (size_t)ns * sizeof(Pack4<T>) + (size_t)nt * 3 * sizeof(Pack4<T>) + (size_t)nm * 2 * sizeof(Pack4<T>);
     b += ((size_t)ns + nt) * sizeof(int);
+    b = (b + 31) & ~(size_t)31;
+    b += (size_t)kSpdRows * kSpdN * sizeof(T);        // the SPD table's slot (1.7 KB in Float64; filled only in spectral mode)
     return (b + 31) & ~(size_t)31;
 }
 
@@ -154,11 +161,17 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
         b.x = m[3]; b.y = m[4]; b.z = m[5]; b.w = m[7];     // emission, roughness
         mat[2 * i] = a; mat[2 * i + 1] = b;
     }
+    const size_t spd_off = (((size_t)g.n_spheres * sizeof(Pack4<T>) + (size_t)g.n_triangles * 3 * sizeof(Pack4<T>) + (size_t)g.n_materials * 2 * sizeof(Pack4<T>) +
+                             ((size_t)g.n_spheres + g.n_triangles) * sizeof(int)) + 31) & ~(size_t)31;
+    T *spd = reinterpret_cast<T *>(lds + spd_off);
+    if (g.spd)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(kSpdRows * kSpdN); i += blockDim.x) spd[i] = g.spd[i];
     __syncthreads();
     SceneLds<T> sc;
     sc.sph = sph; sc.tri = tri; sc.mat = mat; sc.smat = smat; sc.tmat = tmat;
     sc.n_spheres = g.n_spheres; sc.n_triangles = g.n_triangles;
     sc.bvh_nodes = g.bvh_nodes; sc.bvh_tris = g.bvh_tris; sc.n_bvh_tris = g.n_bvh_tris;
+    sc.spd = spd;
     return sc;
 }
 
@@ -365,15 +378,55 @@ template <class T> __device__ __forceinline__ Vec<T> random_in_unit_sphere(const
 //   segment_front : intersection, radiance terms, throughput, everything of the scatter that does not
 //                   need the random vector (o becomes the hit point)
 //   segment_back  : new direction from the pending vector and random_in_unit_sphere()
-enum : uint32_t { kDead = 0, kDiffuse = 1, kSpecRough = 2, kMirror = 3 };
-template <class T> struct Pending { Vec<T> v; T rough; uint32_t kind; };   // v = pos + n (diffuse) | reflected (specular)
+enum : uint32_t { kDead = 0, kDiffuse = 1, kSpecRough = 2, kMirror = 3, kDielectric = 4 };
+template <class T> struct Pending { Vec<T> v; T rough; uint32_t kind; };   // v = pos + n (diffuse) | reflected (specular) | normal (dielectric)
 struct SegInfo { int prim; bool alive; bool has_contrib; };
+
+// ---- extensions (SPIRA_EXT_*; the reference only names them, README.md:10 — the build's own, parity unpinned) ----
+// Compiled into the EXT = true instantiations only; the default kernels do not carry a single instruction of this.
+//   SPIRA_EXT_DIELECTRIC  a material with roughness < 0 is a smooth dielectric of refractive index -roughness, tinted by
+//                         `diffuse`: Snell refraction, Schlick's reflectance, total internal reflection; one uniform draw
+//                         (try 1 of the bounce's key) chooses between reflection and refraction.
+//   SPIRA_EXT_SPECTRAL    hero-wavelength transport: every path draws one wavelength (the third uniform of the pixel-jitter
+//                         try, so no draw is added), RGB reflectances / emissions / the sky are uplifted to that wavelength
+//                         with the basis rows of the SPD table, and the path starts with the wavelength's RGB response
+//                         (rows w) as its throughput, so radiance accumulates as linear sRGB like in the RGB mode.
+template <class T> struct ExtState {
+    uint32_t flags;
+    T bR, bG, bB;            // spectral: the uplift basis at this path's wavelength
+};
+
+template <class T> __device__ __forceinline__ T spd_lookup(const T *tab, int row, int i, T f) {
+    const T *t = tab + row * kSpdN;
+    return t[i] + (t[i + 1] - t[i]) * f;
+}
+// The path's wavelength coordinate x in [0, 35) (380 + 10 x nm) from its bounce-0 key; fills the basis, returns the RGB response.
+template <class T>
+__device__ __forceinline__ Vec<T> ext_wavelength(const SceneLds<T> &sc, uint32_t sA, uint32_t sB, uint32_t pixel, uint32_t sample, ExtState<T> &ext) {
+    T xu, xv, u2;
+    rng3<T>(rng_key(sA, sB, pixel, sample, 0), 0, xu, xv, u2);
+    const T x = u2 * (T)(kSpdN - 1);
+    int i = (int)x;
+    i = i > kSpdN - 2 ? kSpdN - 2 : i;
+    const T f = x - (T)i;
+    ext.bR = spd_lookup<T>(sc.spd, 0, i, f); ext.bG = spd_lookup<T>(sc.spd, 1, i, f); ext.bB = spd_lookup<T>(sc.spd, 2, i, f);
+    return mk<T>(spd_lookup<T>(sc.spd, 3, i, f), spd_lookup<T>(sc.spd, 4, i, f), spd_lookup<T>(sc.spd, 5, i, f));
+}
+template <class T> __device__ __forceinline__ T ext_uplift(const ExtState<T> &ext, const Vec<T> c) { return (c.x * ext.bR + c.y * ext.bG) + c.z * ext.bB; }
 
 // sky term of a miss, :365-366
 template <class T> __device__ __forceinline__ Vec<T> sky_term(const Vec<T> d, const Vec<T> beta) {
     T ts = (T)0.5 * (d.y + (T)1.0);
     Vec<T> sky = mk<T>(1.0, 1.0, 1.0) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts;
     return mulv(beta, sky);
+}
+template <class T, bool EXT> __device__ __forceinline__ Vec<T> sky_term_x(const Vec<T> d, const Vec<T> beta, const ExtState<T> *ext) {
+    if (EXT && (ext->flags & kExtSpectral)) {
+        T ts = (T)0.5 * (d.y + (T)1.0);
+        Vec<T> sky = mk<T>(1.0, 1.0, 1.0) * ((T)1.0 - ts) + mk<T>((T)0.5, (T)0.7, (T)1.0) * ts;
+        return beta * ext_uplift<T>(*ext, sky);
+    }
+    return sky_term<T>(d, beta);
 }
 
 // material index (0-based) of a hit object
@@ -385,9 +438,9 @@ template <class T, bool BVH> __device__ __forceinline__ int material_of(const Sc
 
 // Everything that follows a hit at `pos` (= o + d*t) except the random vector: normal, emitted term, and — when
 // the path scatters — throughput and the pending direction data.  Returns whether the emitted term is non-zero.
-template <class T, bool BVH>
+template <class T, bool BVH, bool EXT = false>
 __device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> pos, const Vec<T> d, int prim, uint32_t slot, Vec<T> &beta,
-                                          bool scatter, Vec<T> &contrib, Pending<T> &pend) {
+                                          bool scatter, Vec<T> &contrib, Pending<T> &pend, const ExtState<T> *ext = nullptr) {
     Vec<T> n;
     if (prim < (int)sc.n_spheres) {
         const Pack4<T> c = sc.sph[prim];
@@ -403,11 +456,18 @@ __device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> po
     const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
     Vec<T> diffuse = mk<T>(ma.x, ma.y, ma.z), emission = mk<T>(mb.x, mb.y, mb.z);
     T specular = ma.w, roughness = mb.w;
+    if (EXT && (ext->flags & kExtSpectral)) {                                // the material at the path's wavelength
+        const T sd = ext_uplift<T>(*ext, diffuse), se = ext_uplift<T>(*ext, emission);
+        diffuse = mk<T>(sd, sd, sd); emission = mk<T>(se, se, se);
+    }
     const bool has_contrib = (emission.x != 0 || emission.y != 0 || emission.z != 0);
     contrib = mulv(beta, emission);                                          // emitted, :339
     pend.kind = kDead; pend.rough = 0; pend.v = mk<T>(0, 0, 0);
     if (scatter) {
-        if (specular > (T)0.0) {                                             // :342
+        if (EXT && (ext->flags & kExtDielectric) && roughness < (T)0.0) {
+            pend.v = n; pend.kind = kDielectric; pend.rough = -roughness;    // direction: dielectric_resolve(), once the key is known
+            beta = mulv(beta, diffuse);
+        } else if (specular > (T)0.0) {                                      // :342
             pend.v = d - n * ((T)2 * dot(d, n));                             // reflect, :323-325, :344
             pend.kind = roughness > (T)0.0 ? kSpecRough : kMirror;           // :346
             pend.rough = roughness;
@@ -421,9 +481,31 @@ __device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> po
     return has_contrib;
 }
 
-template <class T, bool BVH>
+// SPIRA_EXT_DIELECTRIC: turn a pending dielectric interaction (pend.v = geometric normal, pend.rough = refractive index) into
+// its outgoing direction (left in pend.v as a kMirror, i.e. "normalise and go").  u = first uniform of try 1 of the bounce's key.
+template <class T>
+__device__ __forceinline__ void dielectric_resolve(Pending<T> &pend, const Vec<T> d, const RngKey &key) {
+    const Vec<T> n = pend.v;
+    const T ior = pend.rough;
+    const T cosd = dot(d, n);
+    const bool entering = cosd < (T)0.0;
+    const Vec<T> nn = entering ? n : mk<T>(-n.x, -n.y, -n.z);
+    const T eta = entering ? (T)1.0 / ior : ior;
+    const T ci = entering ? -cosd : cosd;
+    const T s2 = (eta * eta) * ((T)1.0 - ci * ci);
+    T r0 = ((T)1.0 - ior) / ((T)1.0 + ior); r0 = r0 * r0;
+    const T x = (T)1.0 - ci, x2 = x * x;
+    const T refl = r0 + ((T)1.0 - r0) * ((x2 * x2) * x);                    // Schlick
+    T u, u1, u2;
+    rng3<T>(key, 1, u, u1, u2);
+    if (s2 > (T)1.0 || u < refl) pend.v = d - nn * ((T)2 * dot(d, nn));      // (total internal) reflection
+    else pend.v = d * eta + nn * (eta * ci - sqrt_rn((T)1.0 - s2));         // Snell
+    pend.kind = kMirror;
+}
+
+template <class T, bool BVH, bool EXT = false>
 __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &o, const Vec<T> d, Vec<T> &beta, bool scatter,
-                                                 Vec<T> &contrib, T &t_out, Pending<T> &pend) {
+                                                 Vec<T> &contrib, T &t_out, Pending<T> &pend, const ExtState<T> *ext = nullptr) {
     SegInfo info;
     T t;
     uint32_t slot;
@@ -432,12 +514,12 @@ __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &
     t_out = prim >= 0 ? t : (T)0;
     if (prim < 0) {                                                          // miss: sky, :365-366
         pend.kind = kDead; pend.rough = 0; pend.v = mk<T>(0, 0, 0);
-        contrib = sky_term<T>(d, beta);
+        contrib = sky_term_x<T, EXT>(d, beta, ext);
         info.alive = false; info.has_contrib = true;
         return info;
     }
     const Vec<T> pos = o + d * t;                                            // point_at, :138 / :183
-    info.has_contrib = shade_hit<T, BVH>(sc, pos, d, prim, slot, beta, scatter, contrib, pend);
+    info.has_contrib = shade_hit<T, BVH, EXT>(sc, pos, d, prim, slot, beta, scatter, contrib, pend, ext);
     info.alive = scatter;
     if (scatter) o = pos;
     return info;
@@ -452,14 +534,16 @@ __device__ __forceinline__ Vec<T> segment_back(const Vec<T> pos, const Pending<T
 }
 
 // Whole segment by one lane (megakernel / trace kernels).
-template <class T, bool BVH>
+template <class T, bool BVH, bool EXT = false>
 __device__ __forceinline__ SegInfo trace_segment(const SceneLds<T> &sc, const RenderConst<T> &rc, Vec<T> &o, Vec<T> &d,
                                                  Vec<T> &beta, uint32_t pixel, uint32_t sample, uint32_t bounce,
-                                                 bool scatter, Vec<T> &contrib, T &t_out) {
+                                                 bool scatter, Vec<T> &contrib, T &t_out, const ExtState<T> *ext = nullptr) {
     Pending<T> pend;
-    SegInfo info = segment_front<T, BVH>(sc, o, d, beta, scatter, contrib, t_out, pend);
+    const Vec<T> d_in = d;
+    SegInfo info = segment_front<T, BVH, EXT>(sc, o, d, beta, scatter, contrib, t_out, pend, ext);
     if (info.alive) {
         Vec<T> rnd = mk<T>(0, 0, 0);
+        if (EXT && pend.kind == kDielectric) dielectric_resolve<T>(pend, d_in, rng_key(rc.sA, rc.sB, pixel, sample, bounce));
         if (pend.kind == kDiffuse || pend.kind == kSpecRough)
             rnd = random_in_unit_sphere<T>(rng_key(rc.sA, rc.sB, pixel, sample, bounce));
         d = segment_back<T>(o, pend, rnd);
@@ -742,7 +826,7 @@ __device__ __forceinline__ uint32_t unpack_q(float w) { return __float_as_uint(w
 __device__ __forceinline__ uint32_t unpack_q(double w) { return (uint32_t)(unsigned long long)__double_as_longlong(w); }
 __device__ __forceinline__ uint32_t unpack_ref(double w) { return (uint32_t)((unsigned long long)__double_as_longlong(w) >> 32); }
 
-template <class T, int R, bool BVH>
+template <class T, int R, bool BVH, bool EXT>
 __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const PathArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
@@ -771,6 +855,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
         for (uint32_t sub = first ? wid : 0u; sub < n_sub; sub += first ? NW : 1u) {
             Vec<T> o[R], beta[R];
             Pending<T> pend[R];
+            ExtState<T> ex[R];                            // EXT instantiations only (dead otherwise)
             uint32_t q[R], ent[R];
             uint32_t n_list = 0;
             // ---------------- phase 1: the hit of segment `stage`
@@ -789,6 +874,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
                         camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
                         beta[r] = mk<T>(1, 1, 1);
+                        if (EXT) { ex[r].flags = rc.flags; if (rc.flags & kExtSpectral) beta[r] = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]); }
                         T t;
                         prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot);      // :335
                         ++n_seg;
@@ -804,17 +890,22 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         if constexpr (kRefArray) ref = rin[region + idx]; else ref = unpack_ref(C.y);
                         prim = (int)ref;
                         if (BVH && ref >= ref_base) { prim = (int)ref_base; slot = ref - ref_base; }
+                        if (EXT) {
+                            path_of<T>(rc, q[r] & 0x7FFFFFFFu, a.pass, pi, pj, pixel, sample);
+                            ex[r].flags = rc.flags;
+                            if (rc.flags & kExtSpectral) (void)ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]);
+                        }
                     }
                     const uint32_t qi = q[r] & 0x7FFFFFFFu;
                     const bool has_l = (q[r] >> 31) != 0;        // only ever set in stages >= 1
                     if (prim < 0) {                              // (stage 0) the camera ray leaves the scene: sky, :365-366
-                        const Vec<T> c = sky_term<T>(d, beta[r]);
+                        const Vec<T> c = sky_term_x<T, EXT>(d, beta[r], &ex[r]);
                         Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
                         a.L[qi] = l;
                         ++n_store;
                     } else {
                         Vec<T> contrib;
-                        const bool has_contrib = shade_hit<T, BVH>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r]);
+                        const bool has_contrib = shade_hit<T, BVH, EXT>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r], &ex[r]);
                         // Path radiance L[q]: while bit 31 of q is clear a term is a plain store (0 + x == x exactly); the
                         // load -> add -> store round trip only remains for paths that met an emitter earlier.
                         if (has_contrib) {
@@ -829,9 +920,10 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                             ++n_store;
                         }
                         want = (pend[r].kind == kDiffuse || pend[r].kind == kSpecRough);
-                        if (want) {
-                            if (!first) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
+                        if (want || (EXT && pend[r].kind == kDielectric)) {
+                            if (!first && !EXT) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
                             key = rng_key(rc.sA, rc.sB, pixel, sample, stage);
+                            if (EXT && pend[r].kind == kDielectric) dielectric_resolve<T>(pend[r], d, key);     // -> kMirror
                         }
                     }
                 }
@@ -894,7 +986,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                     const int prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot);   // :335 of the next level
                     ++n_seg;
                     if (prim < 0) {                               // the path leaves the scene: its last term, :365-366
-                        const Vec<T> c = sky_term<T>(nd, beta[r]);
+                        const Vec<T> c = sky_term_x<T, EXT>(nd, beta[r], &ex[r]);
                         const uint32_t qi = q[r] & 0x7FFFFFFFu;
                         Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
                         if (q[r] >> 31) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + c.x; l.y = l0.y + c.y; l.z = l0.z + c.z; ++n_rmw; }
@@ -938,28 +1030,42 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     }
 }
 
-// Megakernel: one thread walks one whole path in registers (the non-wavefront comparison point).
-template <class T, bool BVH>
+// Megakernel: one lane walks whole paths in registers (the non-wavefront comparison point) — with path REGENERATION: a lane
+// whose path has ended starts its next path at once instead of idling until the longest path of the wave is done, so every
+// trip of the loop intersects one ray per lane (open scenes: 2.2 segments per path on average, 8 at most).
+template <class T, bool BVH, bool EXT>
 __global__ __launch_bounds__(kBlock) void k_mega(const BounceArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
     const RenderConst<T> &rc = a.rc;
     unsigned long long nseg = 0;
-    for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < a.n_first; idx += gridDim.x * kBlock) {
-        uint32_t pixel, sample, pi, pj;
-        Vec<T> o, d, beta = mk<T>(1, 1, 1), Lacc = mk<T>(0, 0, 0);
-        path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
-        camera_ray<T>(rc, pi, pj, pixel, sample, o, d);
-        for (uint32_t b = 0; b < rc.max_depth; ++b) {
-            Vec<T> contrib; T t_hit;
-            SegInfo si = trace_segment<T, BVH>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
-            ++nseg;
-            if (b == 0) { if (si.has_contrib) Lacc = contrib; }
-            else if (si.has_contrib) Lacc = Lacc + contrib;
-            if (!si.alive) break;
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    bool fresh = true;
+    uint32_t pixel = 0, sample = 0, b = 0;
+    Vec<T> o = mk<T>(0, 0, 0), d = mk<T>(0, 0, 1), beta = mk<T>(1, 1, 1), Lacc = mk<T>(0, 0, 0);
+    ExtState<T> ex; ex.flags = rc.flags; ex.bR = 0; ex.bG = 0; ex.bB = 0;
+    while (idx < a.n_first) {
+        if (fresh) {
+            uint32_t pi, pj;
+            path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
+            camera_ray<T>(rc, pi, pj, pixel, sample, o, d);
+            beta = mk<T>(1, 1, 1); Lacc = mk<T>(0, 0, 0); b = 0;
+            if (EXT && (rc.flags & kExtSpectral)) beta = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex);
+            fresh = false;
         }
-        Pack3<T> l; l.x = Lacc.x; l.y = Lacc.y; l.z = Lacc.z;
-        a.L[idx] = l;
+        Vec<T> contrib; T t_hit;
+        SegInfo si = trace_segment<T, BVH, EXT>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit, &ex);
+        ++nseg;
+        if (b == 0) { if (si.has_contrib) Lacc = contrib; }
+        else if (si.has_contrib) Lacc = Lacc + contrib;
+        ++b;
+        if (!si.alive || b == rc.max_depth) {
+            Pack3<T> l; l.x = Lacc.x; l.y = Lacc.y; l.z = Lacc.z;
+            a.L[idx] = l;
+            idx += stride;
+            fresh = true;
+        }
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
     if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
@@ -967,7 +1073,7 @@ __global__ __launch_bounds__(kBlock) void k_mega(const BounceArgs<T> a) {
 
 // Diagnostic: trace chosen paths and record every segment (prim, t, direction) — used by the
 // parity tests to compare path geometry bit for bit with the CPU restatement.
-template <class T, bool BVH>
+template <class T, bool BVH, bool EXT>
 __global__ __launch_bounds__(64) void k_trace(const BounceArgs<T> a, const uint32_t *ijs, uint32_t n_paths, int *prims, T *ts,
                                               T *dirs, T *radiance) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
@@ -979,10 +1085,12 @@ __global__ __launch_bounds__(64) void k_trace(const BounceArgs<T> a, const uint3
     uint32_t pixel = (j - 1) * rc.width + (i - 1);
     Vec<T> o, d, beta = mk<T>(1, 1, 1), Lacc = mk<T>(0, 0, 0);
     camera_ray<T>(rc, i, j, pixel, sample, o, d);
+    ExtState<T> ex; ex.flags = rc.flags; ex.bR = 0; ex.bG = 0; ex.bB = 0;
+    if (EXT && (rc.flags & kExtSpectral)) beta = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex);
     for (uint32_t b = 0; b < rc.max_depth; ++b) {
         Vec<T> contrib; T t_hit;
         Vec<T> dir_in = d;
-        SegInfo si = trace_segment<T, BVH>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit);
+        SegInfo si = trace_segment<T, BVH, EXT>(sc, rc, o, d, beta, pixel, sample, b, b + 1 < rc.max_depth, contrib, t_hit, &ex);
         size_t k = (size_t)p * rc.max_depth + b;
         prims[k] = si.prim; ts[k] = t_hit;
         dirs[3 * k] = dir_in.x; dirs[3 * k + 1] = dir_in.y; dirs[3 * k + 2] = dir_in.z;
@@ -1244,29 +1352,60 @@ __global__ __launch_bounds__(kBlock) void k_variant_cpu(const BounceArgs<T> a) {
 }
 
 // SEM 2 = the .metal kernel's semantics: one lane per pixel walks all spp samples (its LCG state runs through
-// them, .metal :155/:268) and leaves their SUM in accum (the `output_hdr_image[p] += L` of :264).
-template <class T>
+// them, .metal :155/:268) and leaves their SUM in accum (the `output_hdr_image[p] += L` of :264).  The sample and depth loops
+// are flattened into one loop with REGENERATION: a lane whose path has ended starts the pixel's next sample (then its next
+// pixel) at once, so every trip intersects one ray per lane instead of idling behind the wave's longest path.
 // Progressive use (`resume`): start from the sums already in accum and, when rng_states is given, from the LCG
 // states a previous call left there (the `rng_states[pixel_idx] = rng_state` of :268).
+template <class T>
 __global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a, Pack4<T> *accum, uint32_t *rng_states, int resume) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
     const RenderConst<T> &rc = a.rc;
     unsigned long long nseg = 0;
-    for (uint32_t pl = blockIdx.x * kBlock + threadIdx.x; pl < rc.tile_pixels; pl += gridDim.x * kBlock) {
-        uint32_t pixel, sample, pi, pj;
-        path_of<T>(rc, pl, 0, pi, pj, pixel, sample);
-        uint32_t st = ((resume & 2) && rng_states) ? rng_states[pl] : metal_state0(rc.sA, rc.sB, pixel);
-        Vec<T> sum = mk<T>(0, 0, 0);
-        if (resume & 1) { const Pack4<T> l0 = accum[pl]; sum = mk<T>(l0.x, l0.y, l0.z); }
-        for (uint32_t s = 0; s < rc.spp; ++s) {
-            Vec<T> c;
-            nseg += path_metal<T>(sc, rc, pi - 1, pj - 1, st, c, nullptr, nullptr, nullptr);
-            sum = sum + c;
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t pl = blockIdx.x * kBlock + threadIdx.x;
+    bool new_pixel = true, new_path = true;
+    uint32_t pi = 1, pj = 1, st = 0, s = 0, depth = 0;
+    Vec<T> sum = mk<T>(0, 0, 0), acc = mk<T>(0, 0, 0), thr = mk<T>(1, 1, 1), o = mk<T>(0, 0, 0), d = mk<T>(0, 0, 1);
+    while (pl < rc.tile_pixels) {
+        if (new_pixel) {
+            uint32_t pixel, sample;
+            path_of<T>(rc, pl, 0, pi, pj, pixel, sample);
+            st = ((resume & 2) && rng_states) ? rng_states[pl] : metal_state0(rc.sA, rc.sB, pixel);
+            sum = mk<T>(0, 0, 0);
+            if (resume & 1) { const Pack4<T> l0 = accum[pl]; sum = mk<T>(l0.x, l0.y, l0.z); }
+            s = 0; new_pixel = false; new_path = true;
         }
-        Pack4<T> l; l.x = sum.x; l.y = sum.y; l.z = sum.z; l.w = 0;
-        accum[pl] = l;
-        if (rng_states) rng_states[pl] = st;
+        if (new_path) {
+            metal_camera_ray<T>(rc, pi - 1, pj - 1, st, o, d);
+            thr = mk<T>(1, 1, 1); acc = mk<T>(0, 0, 0); depth = 0;
+            new_path = false;
+        }
+        ++nseg;
+        T closest;
+        const int hit = metal_intersect<T>(sc, o, d, closest);
+        bool ended;
+        if (hit == -1) { acc = acc + metal_sky<T>(d, thr); ended = true; }            // :192-198
+        else {
+            o = o + d * closest;                                                      // hit_point, :203
+            Vec<T> emitted; bool has_e;
+            const bool go_on = metal_shade<T>(sc, hit, depth, st, o, d, thr, emitted, has_e);
+            acc = acc + emitted;                                                      // :212
+            ++depth;
+            ended = !go_on || depth == rc.max_depth;
+        }
+        if (ended) {
+            sum = sum + acc;                                                          // output_hdr_image[p] += L, :264
+            new_path = true;
+            if (++s == rc.spp) {
+                Pack4<T> l; l.x = sum.x; l.y = sum.y; l.z = sum.z; l.w = 0;
+                accum[pl] = l;
+                if (rng_states) rng_states[pl] = st;
+                pl += stride;
+                new_pixel = true;
+            }
+        }
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
     if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/spira_hip.h"
+#include "../../include/spira_spd.h"
 #include "spira_device.h"
 #include "spira_bvh.h"
 
@@ -70,6 +71,7 @@ struct Ctx {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf spd32, spd64;                          // SPIRA_EXT_SPECTRAL: the SPD table, uploaded once per precision
     DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
     SceneStore scene;                         // the scene of the current call (host-array entry points)
     spira::Stats *h_stats = nullptr;          // pinned
@@ -176,6 +178,10 @@ int validate_params(const void *camera12, const spira_params *p, uint32_t nt, ui
     if (sem != SPIRA_SEM_A && nt) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_CPU / SPIRA_SEM_METAL are sphere-only, like their sources");
     uint32_t kern = p->flags & SPIRA_KERNEL_MASK;
     if (kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA && kern != SPIRA_KERNEL_BOUNCE) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
+    if (p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) {
+        if (sem != SPIRA_SEM_A) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_EXT_* extensions apply to SPIRA_SEM_A only");
+        if (kern == SPIRA_KERNEL_BOUNCE) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_EXT_* extensions are not built into the per-bounce organisation");
+    }
     uint32_t rows = p->rows;
     if (rows == 0) rows = p->height;
     else if (p->stripe_count > 1) {
@@ -298,8 +304,12 @@ void launch_bounce(int R, dim3 grid, size_t lds, hipStream_t st, const spira::Bo
 template <class T>
 void launch_path(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<T> &a) {
     const bool bvh = a.scene.n_bvh_tris != 0;
-    if (R == 2) { if (bvh) launch_lds(spira::k_path<T, 2, true>, grid, dim3(spira::kBlock), lds, st, a); else launch_lds(spira::k_path<T, 2, false>, grid, dim3(spira::kBlock), lds, st, a); }
-    else        { if (bvh) launch_lds(spira::k_path<T, 1, true>, grid, dim3(spira::kBlock), lds, st, a); else launch_lds(spira::k_path<T, 1, false>, grid, dim3(spira::kBlock), lds, st, a); }
+    const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
+    const dim3 blk(spira::kBlock);
+    if (ext) {           // extension instantiations (R = 2 only)
+        if (bvh) launch_lds(spira::k_path<T, 2, true, true>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, true>, grid, blk, lds, st, a);
+    } else if (R == 2) { if (bvh) launch_lds(spira::k_path<T, 2, true, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, false>, grid, blk, lds, st, a); }
+    else               { if (bvh) launch_lds(spira::k_path<T, 1, true, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 1, false, false>, grid, blk, lds, st, a); }
 }
 
 int profile_events(Ctx &c, size_t need) {
@@ -331,6 +341,25 @@ int acquire_scene(Ctx &c, hipStream_t st, const spira_scene *h, const T *spheres
     const uint32_t nt = triangles10 ? p->n_triangles : 0;
     if (int rc = scene_upload<T>(c.scene, st, c.have_done ? c.ev_done : nullptr, spheres5, materials8, triangles10, p->n_spheres, p->n_materials, nt)) return rc;
     scene_pointers<T>(c.scene, g);
+    return 0;
+}
+
+// SPIRA_EXT_SPECTRAL: the SPD table of include/spira_spd.h in the render precision, resident per context.
+template <class T>
+int attach_spd(Ctx &c, hipStream_t st, const spira_params *p, spira::SceneGlobal<T> &g) {
+    g.spd = nullptr;
+    if (!(p->flags & SPIRA_EXT_SPECTRAL)) return 0;
+    DevBuf &b = sizeof(T) == 4 ? c.spd32 : c.spd64;
+    if (!b.p) {
+        static_assert(SPIRA_SPD_N == spira::kSpdN && SPIRA_SPD_ROWS == spira::kSpdRows, "SPD table shape");
+        T host[SPIRA_SPD_ROWS * SPIRA_SPD_N];
+        for (int r = 0; r < SPIRA_SPD_ROWS; ++r)
+            for (int i = 0; i < SPIRA_SPD_N; ++i) host[r * SPIRA_SPD_N + i] = (T)spira_spd_table[r][i];
+        if (int rc = b.ensure(sizeof host)) return rc;
+        HIP_TRY(hipMemcpy(b.p, host, sizeof host, hipMemcpyHostToDevice));
+    }
+    (void)st;
+    g.spd = (const T *)b.p;
     return 0;
 }
 
@@ -419,6 +448,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
 
     spira::BounceArgs<T> a{};
     if (int rc = acquire_scene<T>(c, st, h, spheres5, materials8, triangles10, p, a.scene)) return rc;
+    if (int rc = attach_spd<T>(c, st, p, a.scene)) return rc;
     fill_const<T>(a.rc, camera12, p, rows, slots);
     if (!fastdiv_selfcheck(a.rc.tile_pixels, (uint32_t)batch) || !fastdiv_selfcheck(a.rc.width, a.rc.tile_pixels) ||
         !fastdiv_selfcheck(a.rc.stripe_h ? a.rc.stripe_h : 1, rows))
@@ -520,8 +550,9 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 ++launches;
             } else if (mega) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
-                if (a.scene.n_bvh_tris) launch_lds(spira::k_mega<T, true>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
-                else launch_lds(spira::k_mega<T, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
+                const bool ext = (p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
+                if (a.scene.n_bvh_tris) { if (ext) launch_lds(spira::k_mega<T, true, true>, dim3(blocks), dim3(spira::kBlock), lds, st, a); else launch_lds(spira::k_mega<T, true, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a); }
+                else { if (ext) launch_lds(spira::k_mega<T, false, true>, dim3(blocks), dim3(spira::kBlock), lds, st, a); else launch_lds(spira::k_mega<T, false, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a); }
                 ++launches;
             } else if (persistent) {
                 // one launch: every wave walks all max_depth stages on its own region of the hit queues
@@ -621,6 +652,7 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     if (int rc = order_after_previous(c, st)) return rc;
     spira::BounceArgs<T> a{};
     if (int rc = acquire_scene<T>(c, st, (const spira_scene *)nullptr, spheres5, materials8, triangles10, p, a.scene)) return rc;
+    if (int rc = attach_spd<T>(c, st, p, a.scene)) return rc;
     fill_const<T>(a.rc, camera12, p, rows, 1);
     size_t nseg = (size_t)n_paths * p->max_depth;
     size_t b_ij = ((size_t)n_paths * 3 * sizeof(uint32_t) + 255) & ~(size_t)255;
@@ -641,8 +673,12 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     const uint32_t sem = p->flags & SPIRA_SEM_MASK;
     if (sem == SPIRA_SEM_CPU) launch_lds(spira::k_trace_variant<T, 1>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
     else if (sem == SPIRA_SEM_METAL) launch_lds(spira::k_trace_variant<T, 2>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
-    else if (a.scene.n_bvh_tris) launch_lds(spira::k_trace<T, true>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
-    else launch_lds(spira::k_trace<T, false>, dim3((n_paths + 63) / 64), dim3(64), lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra);
+    else {
+        const bool ext = (p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
+        const dim3 tg((n_paths + 63) / 64), tb(64);
+        if (a.scene.n_bvh_tris) { if (ext) launch_lds(spira::k_trace<T, true, true>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); else launch_lds(spira::k_trace<T, true, false>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); }
+        else { if (ext) launch_lds(spira::k_trace<T, false, true>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); else launch_lds(spira::k_trace<T, false, false>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); }
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(prims, d_pr, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ts, d_ts, nseg * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -942,7 +978,7 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qX[i].release(); }
-        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release();
+        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
         (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop); (void)hipEventDestroy(c.ev_done);

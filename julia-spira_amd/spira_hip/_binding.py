@@ -20,6 +20,7 @@ KERNEL_WAVEFRONT, KERNEL_MEGA, KERNEL_BOUNCE = 0x00, 0x10, 0x20
 POST_ACES, POST_ACES_GAMMA, POST_CLAMP_GAMMA, POST_NONE = 0x000, 0x100, 0x200, 0x300
 ROWS_BOTTOM_UP = 0x1000
 FLAG_PROFILE = 0x10000
+EXT_DIELECTRIC, EXT_SPECTRAL = 0x20000, 0x40000
 
 EXPORTS = [
     "spira_abi_version", "spira_last_error", "spira_device_count", "spira_set_device", "spira_get_counters",

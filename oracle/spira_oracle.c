@@ -27,6 +27,7 @@
 #endif
 
 #include "../include/spira_hip.h" /* plain-data spira_params + flag values only */
+#include "../include/spira_spd.h" /* the SPD table of the spectral extension: data shared with the product */
 
 #define ORACLE_MAX_TRIES 64u
 

@@ -54,6 +54,7 @@ typedef struct {
     uint32_t sA, sB;          /* seed halves after oracle_seed_mix */
     uint32_t max_depth;
     uint32_t sem;
+    uint32_t ext;             /* SPIRA_EXT_* bits (the build's own extensions; no reference code exists for them) */
 } SUF(World);
 #define World SUF(World)
 
@@ -198,13 +199,38 @@ static inline V3 SUF(reflect)(V3 v, V3 n) {
     return SUF(sub)(v, SUF(scale)(n, (REAL)2 * SUF(dot)(v, n)));
 }
 
+/* ---- SPIRA_EXT_SPECTRAL (include/spira_hip.h): the path's wavelength and the uplift of an RGB triple to it.  The SPD table is
+ * data shared with the product (include/spira_spd.h, generated by tools/make_spd_table.py); the arithmetic on it is restated here. */
+typedef struct { REAL bR, bG, bB; } SUF(Basis);
+#define Basis SUF(Basis)
+static inline REAL SUF(spd_lookup)(int row, int i, REAL f) {
+    REAL t0 = (REAL)spira_spd_table[row][i], t1 = (REAL)spira_spd_table[row][i + 1];
+    return t0 + (t1 - t0) * f;
+}
+static V3 SUF(wavelength)(REAL u2, Basis *b) {       /* returns the wavelength's weighted linear-sRGB response */
+    REAL x = u2 * (REAL)(SPIRA_SPD_N - 1);
+    int i = (int)x;
+    if (i > SPIRA_SPD_N - 2) i = SPIRA_SPD_N - 2;
+    REAL f = x - (REAL)i;
+    b->bR = SUF(spd_lookup)(0, i, f); b->bG = SUF(spd_lookup)(1, i, f); b->bB = SUF(spd_lookup)(2, i, f);
+    return SUF(v3)(SUF(spd_lookup)(3, i, f), SUF(spd_lookup)(4, i, f), SUF(spd_lookup)(5, i, f));
+}
+static inline REAL SUF(uplift)(const Basis *b, V3 c) { return (c.x * b->bR + c.y * b->bG) + c.z * b->bB; }
+
 /* Optional per-segment trace of one path (tests compare geometry bit for bit). */
 typedef struct { int prim; REAL t; REAL dir[3]; } SUF(TraceSeg);
 #define TraceSeg SUF(TraceSeg)
 
 /* ray_color: examples/julia-raytracer.jl:328-367 (recursive, like the reference) */
+static V3 SUF(ray_color_x)(const World *w, Ray ray, int depth, uint32_t pixel, uint32_t sample,
+                           uint64_t *segments, TraceSeg *trace, const Basis *basis);
 static V3 SUF(ray_color)(const World *w, Ray ray, int depth, uint32_t pixel, uint32_t sample,
                          uint64_t *segments, TraceSeg *trace) {
+    return SUF(ray_color_x)(w, ray, depth, pixel, sample, segments, trace, NULL);
+}
+/* `basis` non-NULL = spectral mode: every RGB triple of the scene is replaced by its value at the path's wavelength. */
+static V3 SUF(ray_color_x)(const World *w, Ray ray, int depth, uint32_t pixel, uint32_t sample,
+                           uint64_t *segments, TraceSeg *trace, const Basis *basis) {
     if (depth <= 0) return SUF(v3)(0, 0, 0);                                      /* :330 */
     uint32_t bounce = w->max_depth - (uint32_t)depth;
     if (segments) ++*segments;
@@ -216,27 +242,55 @@ static V3 SUF(ray_color)(const World *w, Ray ray, int depth, uint32_t pixel, uin
     }
     if (rec.hit) {                                                                /* :337 */
         Material m = SUF(get_material)(w, rec.material);
+        if (basis) {                                                              /* SPIRA_EXT_SPECTRAL */
+            REAL sd = SUF(uplift)(basis, m.diffuse), se = SUF(uplift)(basis, m.emission);
+            m.diffuse = SUF(v3)(sd, sd, sd); m.emission = SUF(v3)(se, se, se);
+        }
         V3 emitted = m.emission;                                                  /* :339 */
         RngKey k = SUF(rng_key)(w, pixel, sample, bounce);
+        if ((w->ext & SPIRA_EXT_DIELECTRIC) && m.roughness < (REAL)0.0) {         /* SPIRA_EXT_DIELECTRIC: Snell + Schlick */
+            V3 n = rec.normal, d = ray.direction;
+            REAL ior = -m.roughness;
+            REAL cosd = SUF(dot)(d, n);
+            int entering = cosd < (REAL)0.0;
+            V3 nn = entering ? n : SUF(v3)(-n.x, -n.y, -n.z);
+            REAL eta = entering ? (REAL)1.0 / ior : ior;
+            REAL ci = entering ? -cosd : cosd;
+            REAL s2 = (eta * eta) * ((REAL)1.0 - ci * ci);
+            REAL r0 = ((REAL)1.0 - ior) / ((REAL)1.0 + ior); r0 = r0 * r0;
+            REAL x = (REAL)1.0 - ci, x2 = x * x;
+            REAL refl = r0 + ((REAL)1.0 - r0) * ((x2 * x2) * x);
+            REAL u, u1, u2;
+            SUF(rng3)(k, 1, &u, &u1, &u2);
+            V3 dir;
+            if (s2 > (REAL)1.0 || u < refl) dir = SUF(sub)(d, SUF(scale)(nn, (REAL)2 * SUF(dot)(d, nn)));
+            else dir = SUF(add)(SUF(scale)(d, eta), SUF(scale)(nn, eta * ci - SQRT((REAL)1.0 - s2)));
+            Ray scattered; scattered.origin = rec.position;
+            scattered.direction = SUF(normalize)(dir);
+            V3 in = SUF(ray_color_x)(w, scattered, depth - 1, pixel, sample, segments, trace, basis);
+            return SUF(add)(emitted, SUF(mulv)(in, m.diffuse));
+        }
         if (m.specular > (REAL)0.0) {                                             /* :342 */
             V3 reflected = SUF(reflect)(ray.direction, rec.normal);               /* :344 */
             if (m.roughness > (REAL)0.0)                                          /* :346 */
                 reflected = SUF(add)(reflected, SUF(scale)(SUF(random_in_unit_sphere)(k), m.roughness)); /* :347 */
             Ray scattered; scattered.origin = rec.position;
             scattered.direction = SUF(normalize)(reflected);                      /* :349 */
-            V3 specular_color = SUF(ray_color)(w, scattered, depth - 1, pixel, sample, segments, trace); /* :352 */
+            V3 specular_color = SUF(ray_color_x)(w, scattered, depth - 1, pixel, sample, segments, trace, basis); /* :352 */
             return SUF(add)(emitted, SUF(mulv)(SUF(scale)(specular_color, m.specular), m.diffuse));      /* :353 */
         } else {
             V3 target = SUF(add)(SUF(add)(rec.position, rec.normal), SUF(random_in_unit_sphere)(k));    /* :356 */
             Ray scattered; scattered.origin = rec.position;
             scattered.direction = SUF(normalize)(SUF(sub)(target, rec.position)); /* :357 */
-            V3 in = SUF(ray_color)(w, scattered, depth - 1, pixel, sample, segments, trace);
+            V3 in = SUF(ray_color_x)(w, scattered, depth - 1, pixel, sample, segments, trace, basis);
             return SUF(add)(emitted, SUF(mulv)(SUF(scale)(in, (REAL)0.5), m.diffuse));                  /* :360 */
         }
     }
     REAL t = (REAL)0.5 * (ray.direction.y + (REAL)1.0);                           /* :365 */
-    return SUF(add)(SUF(scale)(SUF(v3)(1.0, 1.0, 1.0), (REAL)1.0 - t),
-                    SUF(scale)(SUF(v3)((REAL)0.5, (REAL)0.7, (REAL)1.0), t));     /* :366 */
+    V3 sky = SUF(add)(SUF(scale)(SUF(v3)(1.0, 1.0, 1.0), (REAL)1.0 - t),
+                      SUF(scale)(SUF(v3)((REAL)0.5, (REAL)0.7, (REAL)1.0), t));   /* :366 */
+    if (basis) { REAL ss = SUF(uplift)(basis, sky); return SUF(v3)(ss, ss, ss); }
+    return sky;
 }
 
 /* to_acescg: examples/julia-raytracer.jl:370-384 (clamp, no gamma) */
@@ -266,6 +320,7 @@ static void SUF(world_init)(World *w, const REAL *spheres5, const REAL *material
     oracle_seed_mix(p->seed, &w->sA, &w->sB);
     w->max_depth = p->max_depth;
     w->sem = p->flags & SPIRA_SEM_MASK;
+    w->ext = p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL);
 }
 
 /* One sample of one pixel: the body of the sample loop, examples/julia-raytracer.jl:398-401.
@@ -278,6 +333,11 @@ static V3 SUF(sample_pixel)(const World *w, const spira_params *p, uint32_t i, u
     REAL u = ((REAL)(i - 1) + xi_u) / (REAL)(p->width - 1);                       /* :398 */
     REAL v = ((REAL)(j - 1) + xi_v) / (REAL)(p->height - 1);                      /* :399 */
     Ray ray = SUF(get_ray)(w, u, v);                                              /* :400 */
+    if (w->ext & SPIRA_EXT_SPECTRAL) {       /* the path's wavelength is the jitter try's third uniform; radiance -> linear sRGB */
+        Basis basis;
+        V3 resp = SUF(wavelength)(unused, &basis);
+        return SUF(mulv)(resp, SUF(ray_color_x)(w, ray, (int)p->max_depth, pixel, sample, segments, trace, &basis));
+    }
     return SUF(ray_color)(w, ray, (int)p->max_depth, pixel, sample, segments, trace); /* :401 */
 }
 
@@ -681,3 +741,4 @@ void SUF(oracle_sincos_turn)(REAL r, REAL *sc2) { SUF(sincos_turn)(r, &sc2[0], &
 #undef World
 #undef RngKey
 #undef TraceSeg
+#undef Basis
