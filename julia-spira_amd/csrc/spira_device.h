@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "spira_fastdiv.h"
 
 namespace spira {
 
@@ -176,27 +177,6 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
 }
 
 // ------------------------------------------------------------------ per-render constants
-// Division by a launch constant: Granlund-Montgomery round-up method, exact for every uint32 n and
-// d >= 1 (one v_mul_hi_u32 instead of the ~20-instruction udiv expansion; path_of runs per segment).
-struct FastDiv { uint32_t magic, sh1, sh2; };
-__host__ inline FastDiv fastdiv_make(uint32_t d) {
-    FastDiv f;
-    uint32_t l = 0;
-    while (l < 32 && (1ull << l) < d) ++l;                       // l = ceil(log2 d)
-    f.magic = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
-    f.sh1 = l < 1 ? l : 1;
-    f.sh2 = l ? l - 1 : 0;
-    return f;
-}
-__host__ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDiv &f) {
-#ifdef __HIP_DEVICE_COMPILE__
-    uint32_t t = __umulhi(f.magic, n);
-#else
-    uint32_t t = (uint32_t)(((uint64_t)f.magic * n) >> 32);
-#endif
-    return (t + ((n - t) >> f.sh1)) >> f.sh2;
-}
-
 template <class T> struct RenderConst {
     FastDiv fd_tile, fd_width, fd_stripe;   // tile_pixels, width, stripe_h
     Vec<T> cam_origin, cam_llc, cam_hor, cam_ver;

@@ -25,6 +25,7 @@
 #include "../../include/spira_spd.h"
 #include "spira_device.h"
 #include "spira_bvh.h"
+#include "spira_validate.h"
 
 
 namespace {
@@ -142,26 +143,15 @@ uint32_t stripe_rows(uint32_t height, uint32_t sh, uint32_t n, uint32_t r) {
     return rows;
 }
 
-// Scene arrays: pointers, counts, LDS budget and material indices (everything that does not depend on the render parameters).
+// Scene arrays: pointers, counts, material indices, finiteness (spira_validate.h) and the LDS budget.
 template <class T>
 int validate_scene(const T *spheres5, const T *materials8, const T *triangles10, uint32_t n_spheres, uint32_t n_materials, uint32_t nt) {
-    if (!materials8) return fail(SPIRA_E_INVALID, "materials8 is NULL");
-    if (n_spheres && !spheres5) return fail(SPIRA_E_INVALID, "spheres5 is NULL");
-    if (n_materials < 1) return fail(SPIRA_E_INVALID, "n_materials must be >= 1");
     if (n_spheres > SPIRA_MAX_LDS_SPHERES) return fail(SPIRA_E_LIMIT, "more than 1024 spheres");
     if (nt > SPIRA_MAX_TRIANGLES) return fail(SPIRA_E_LIMIT, "more than 2^24 triangles");
+    const char *msg = nullptr;
+    if (int rc = spira::scene_arrays_check<T>(spheres5, materials8, triangles10, n_spheres, n_materials, nt, &msg)) return fail(rc, msg);
     if (spira::scene_lds_bytes<T>(n_spheres, n_materials, nt > SPIRA_LDS_TRIANGLES ? 0 : nt) > 120 * 1024)
         return fail(SPIRA_E_LIMIT, "scene does not fit in LDS");
-    for (uint32_t i = 0; i < n_spheres; ++i) {
-        T m = spheres5[5 * (size_t)i + 4];
-        if (!(m >= 1 && m <= (T)n_materials) || m != std::floor(m))
-            return fail(SPIRA_E_INVALID, "sphere material index out of range (1-based, stored as a float)");
-    }
-    for (uint32_t i = 0; i < nt; ++i) {
-        T m = triangles10[10 * (size_t)i + 9];
-        if (!(m >= 1 && m <= (T)n_materials) || m != std::floor(m))
-            return fail(SPIRA_E_INVALID, "triangle material index out of range");
-    }
     return 0;
 }
 

@@ -1,0 +1,245 @@
+// host_sanitize.cpp — host-only harness built with -fsanitize=address,undefined (tests/test_native_sanitize.py).
+// GPU AddressSanitizer is not available on the pool, so everything of the product that runs on the HOST is exercised here
+// under ASan + UBSan: the BVH builder (spira_bvh.h) over degenerate meshes, the scene validation (spira_validate.h), the
+// magic-number division (spira_fastdiv.h) and the triangle hash; the CPU oracle is linked in and run under the sanitizers too.
+// The tree is checked semantically: a host traversal with the kernels' rules (ordered descent, conservative slab test, leaf =
+// Moller-Trumbore, ties to the later triangle) must return exactly what a linear scan over the caller's array returns.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../julia-spira_amd/csrc/spira_bvh.h"
+#include "../../julia-spira_amd/csrc/spira_fastdiv.h"
+#include "../../julia-spira_amd/csrc/spira_validate.h"
+#include "../../include/spira_hip.h"
+
+extern "C" {
+int oracle_render_f64(const double *, const double *, const double *, const double *, const spira_params *, double *, double *, int, uint64_t *);
+int oracle_render_f32(const float *, const float *, const float *, const float *, const spira_params *, float *, float *, int, uint64_t *);
+int oracle_render_variant_f32(const float *, const float *, const float *, const spira_params *, float *, float *, int, uint64_t *);
+}
+
+static int g_fail = 0;
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
+
+template <class T> struct V { T x, y, z; };
+template <class T> static V<T> sub(V<T> a, V<T> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class T> static V<T> cross(V<T> a, V<T> b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+template <class T> static T dot(V<T> a, V<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// examples/julia-raytracer.jl:145-187 on precomputed edges (same statements as triangle_test of spira_device.h)
+template <class T> static bool tri_test(V<T> v0, V<T> e1, V<T> e2, V<T> o, V<T> d, T t_min, T t_max, T &t_out) {
+    V<T> h = cross(d, e2);
+    T a = dot(e1, h);
+    if (std::fabs(a) < (T)1e-8) return false;
+    T f = (T)1.0 / a;
+    V<T> s = sub(o, v0);
+    T u = f * dot(s, h);
+    if (u < 0 || u > 1) return false;
+    V<T> q = cross(s, e1);
+    T v = f * dot(d, q);
+    if (v < 0 || u + v > 1) return false;
+    T t = f * dot(e2, q);
+    if (t < t_min || t > t_max) return false;
+    t_out = t;
+    return true;
+}
+
+template <class T> static uint32_t bits_of(T w) {
+    if (sizeof(T) == 4) { uint32_t u; std::memcpy(&u, &w, 4); return u; }
+    uint64_t u; std::memcpy(&u, &w, 8); return (uint32_t)u;
+}
+
+template <class T>
+static void traverse(const std::vector<spira::HostPack4<T>> &nodes, const std::vector<spira::HostPack4<T>> &tris, V<T> o, V<T> d, T t_min, T &closest, int &prim) {
+    const V<T> inv = {(T)1 / d.x, (T)1 / d.y, (T)1 / d.z};
+    auto entry = [&](const spira::HostPack4<T> &mn, const spira::HostPack4<T> &mx) -> T {
+        T x1 = (mn.x - o.x) * inv.x, x2 = (mx.x - o.x) * inv.x, y1 = (mn.y - o.y) * inv.y, y2 = (mx.y - o.y) * inv.y, z1 = (mn.z - o.z) * inv.z, z2 = (mx.z - o.z) * inv.z;
+        T en = std::fmax(std::fmax(std::fmin(x1, x2), std::fmin(y1, y2)), std::fmin(z1, z2));
+        T ex = std::fmin(std::fmin(std::fmax(x1, x2), std::fmax(y1, y2)), std::fmax(z1, z2));
+        return (en <= ex && ex >= 0 && en <= closest) ? std::fmax(en, (T)0) : (T)-1;
+    };
+    uint32_t stack[spira::kBvhStack];
+    int sp = 0;
+    uint32_t ref = 0;
+    while (true) {
+        if (ref & spira::kBvhLeafFlag) {
+            uint32_t first = ref & 0x00FFFFFFu, cnt = (ref >> 24) & 0x7Fu;
+            CHECK(cnt >= 1 && cnt <= spira::kBvhMaxLeaf && (size_t)(first + cnt) * 3 <= tris.size());
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                const auto &a = tris[3 * (size_t)i], &b = tris[3 * (size_t)i + 1], &c = tris[3 * (size_t)i + 2];
+                T t;
+                if (tri_test<T>({a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}, o, d, t_min, closest, t)) {
+                    int p = (int)bits_of(a.w);
+                    if (t < closest || p > prim) { closest = t; prim = p; }
+                }
+            }
+        } else {
+            CHECK((size_t)ref * 4 + 3 < nodes.size());
+            const auto &l0 = nodes[4 * (size_t)ref], &l1 = nodes[4 * (size_t)ref + 1], &r0 = nodes[4 * (size_t)ref + 2], &r1 = nodes[4 * (size_t)ref + 3];
+            T tl = entry(l0, l1), tr = entry(r0, r1);
+            uint32_t lref = bits_of(l0.w), rref = bits_of(r0.w);
+            bool hl = tl >= 0 && lref != spira::kBvhNone, hr = tr >= 0 && rref != spira::kBvhNone;
+            if (hl && hr) { bool lf = tl <= tr; CHECK(sp < spira::kBvhStack); stack[sp++] = lf ? rref : lref; ref = lf ? lref : rref; continue; }
+            if (hl) { ref = lref; continue; }
+            if (hr) { ref = rref; continue; }
+        }
+        if (sp == 0) break;
+        ref = stack[--sp];
+    }
+}
+
+template <class T>
+static void check_mesh(const char *name, const std::vector<T> &t10, uint32_t n_rays, uint32_t seed) {
+    const uint32_t n = (uint32_t)(t10.size() / 10);
+    std::vector<spira::HostPack4<T>> nodes, tris;
+    int depth = 0;
+    const bool ok = spira::bvh_build<T>(t10.data(), n, nodes, tris, &depth);
+    CHECK(ok);
+    if (!ok) return;
+    CHECK(tris.size() == 3 * (size_t)n && nodes.size() >= 4 && nodes.size() % 4 == 0 && depth < spira::kBvhStack - 2);
+    std::vector<char> seen(n, 0);                       // every triangle exactly once
+    for (uint32_t i = 0; i < n; ++i) { uint32_t oi = bits_of(tris[3 * (size_t)i].w); CHECK(oi < n && !seen[oi]); if (oi < n) seen[oi] = 1; }
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<double> U(-1, 1);
+    uint32_t hits = 0;
+    for (uint32_t r = 0; r < n_rays; ++r) {
+        const uint32_t k = rng() % n;                   // aim at a random triangle's first vertex (+ noise) from a random origin
+        V<T> o = {(T)(4 * U(rng)), (T)(4 * U(rng)), (T)(4 * U(rng))};
+        V<T> tgt = {t10[10 * (size_t)k] + (T)(0.3 * U(rng)), t10[10 * (size_t)k + 1] + (T)(0.3 * U(rng)), t10[10 * (size_t)k + 2] + (T)(0.3 * U(rng))};
+        V<T> d = sub(tgt, o);
+        T len = std::sqrt(dot(d, d));
+        if (!(len > 0)) continue;
+        d = {d.x / len, d.y / len, d.z / len};
+        T c_lin = INFINITY; int p_lin = -1;
+        for (uint32_t i = 0; i < n; ++i) {              // examples/julia-raytracer.jl:242-258
+            const T *t = &t10[10 * (size_t)i];
+            V<T> v0 = {t[0], t[1], t[2]}, e1 = {(T)(t[3] - t[0]), (T)(t[4] - t[1]), (T)(t[5] - t[2])}, e2 = {(T)(t[6] - t[0]), (T)(t[7] - t[1]), (T)(t[8] - t[2])};
+            T tt;
+            if (tri_test<T>(v0, e1, e2, o, d, (T)0.001, c_lin, tt)) { c_lin = tt; p_lin = (int)i; }
+        }
+        T c_bvh = INFINITY; int p_bvh = -1;
+        traverse<T>(nodes, tris, o, d, (T)0.001, c_bvh, p_bvh);
+        CHECK(p_lin == p_bvh && (p_lin < 0 || std::memcmp(&c_lin, &c_bvh, sizeof(T)) == 0));
+        hits += p_lin >= 0;
+    }
+    std::printf("%-28s n=%-7u nodes=%-7zu depth=%-3d rays=%u hits=%u\n", name, n, nodes.size() / 4, depth, n_rays, hits);
+}
+
+template <class T> static std::vector<T> soup(uint32_t n, uint32_t seed, double size) {
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<double> U(-1, 1);
+    std::vector<T> t(10 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        double b[3] = {3 * U(rng), 3 * U(rng), 3 * U(rng)};
+        for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) t[10 * (size_t)i + 3 * v + k] = (T)(b[k] + (v ? size * U(rng) : 0));
+        t[10 * (size_t)i + 9] = 1;
+    }
+    return t;
+}
+
+template <class T> static void meshes() {
+    check_mesh<T>("random soup", soup<T>(3000, 1, 0.8), 3000, 11);
+    check_mesh<T>("one triangle", soup<T>(1, 2, 1.0), 300, 12);
+    check_mesh<T>("two triangles", soup<T>(2, 3, 1.0), 300, 13);
+    {   // 300 copies of the same triangle: all centroids coincide, leaves would overflow without the list split; ties -> the LAST copy
+        std::vector<T> one = soup<T>(1, 4, 1.5), t;
+        for (int i = 0; i < 300; ++i) t.insert(t.end(), one.begin(), one.end());
+        check_mesh<T>("300 identical triangles", t, 400, 14);
+    }
+    {   // zero-area triangles (two equal vertices / all three equal) mixed into a soup
+        std::vector<T> t = soup<T>(500, 5, 0.7);
+        for (uint32_t i = 0; i < 500; i += 5) for (int k = 0; k < 3; ++k) { t[10 * (size_t)i + 3 + k] = t[10 * (size_t)i + k]; if (i % 10 == 0) t[10 * (size_t)i + 6 + k] = t[10 * (size_t)i + k]; }
+        check_mesh<T>("zero-area triangles", t, 1500, 15);
+    }
+    {   // a flat grid (all z equal: one axis has zero extent) with many equal centroids per cell (each cell's triangle repeated 5 times)
+        std::vector<T> t;
+        for (int gx = 0; gx < 20; ++gx) for (int gy = 0; gy < 20; ++gy) for (int rep = 0; rep < 5; ++rep) {
+            T x = (T)(gx * 0.25 - 2.5), y = (T)(gy * 0.25 - 2.5);
+            T tri[10] = {x, y, 0, (T)(x + 0.25), y, 0, x, (T)(y + 0.25), 0, 1};
+            t.insert(t.end(), tri, tri + 10);
+        }
+        check_mesh<T>("flat grid, repeated cells", t, 2000, 16);
+    }
+    {   // huge coordinate range: padding and the slab test must stay conservative
+        std::vector<T> t = soup<T>(400, 6, 0.5);
+        for (size_t i = 0; i < t.size(); ++i) if (i % 10 != 9) t[i] *= (i / 10 % 2 ? (T)1000 : (T)0.001);
+        check_mesh<T>("mixed scales", t, 1000, 17);
+    }
+}
+
+static void fastdiv_checks() {
+    std::mt19937 rng(7);
+    const uint32_t ds[] = {1, 2, 3, 5, 7, 8, 64, 1000, 1920, 2073600, 132710400, 0x7FFFFFFF, 0x80000000u, 0xFFFFFFFFu};
+    for (uint32_t d : ds) {
+        const spira::FastDiv f = spira::fastdiv_make(d);
+        const uint32_t probes[] = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 0x7FFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFFu};
+        for (uint32_t n : probes) CHECK(spira::fastdiv(n, f) == n / d);
+        for (int i = 0; i < 20000; ++i) { uint32_t n = rng(); CHECK(spira::fastdiv(n, f) == n / d); }
+    }
+    for (int i = 0; i < 20000; ++i) { uint32_t d = rng() | 1u, n = rng(); CHECK(spira::fastdiv(n, spira::fastdiv_make(d)) == n / d); }
+    unsigned char buf[37];
+    for (int i = 0; i < 37; ++i) buf[i] = (unsigned char)(i * 7);
+    uint64_t h0 = spira::bytes_hash64(buf, 0), h1 = spira::bytes_hash64(buf + 1, 36), h2 = spira::bytes_hash64(buf, 37);    // unaligned start, odd length
+    CHECK(h0 != h1 && h1 != h2);
+}
+
+static void validation_checks() {
+    const char *msg = nullptr;
+    float s5[10] = {0, 0, 0, 1, 1, 1, 1, 1, 0.5f, 2}, m8[16] = {0};
+    CHECK(spira::scene_arrays_check<float>(s5, m8, nullptr, 2, 2, 0, &msg) == 0);
+    s5[9] = 3; CHECK(spira::scene_arrays_check<float>(s5, m8, nullptr, 2, 2, 0, &msg) == SPIRA_E_INVALID);
+    s5[9] = 1.5f; CHECK(spira::scene_arrays_check<float>(s5, m8, nullptr, 2, 2, 0, &msg) == SPIRA_E_INVALID);
+    s5[9] = NAN; CHECK(spira::scene_arrays_check<float>(s5, m8, nullptr, 2, 2, 0, &msg) == SPIRA_E_INVALID);
+    s5[9] = 2; s5[5] = INFINITY; CHECK(spira::scene_arrays_check<float>(s5, m8, nullptr, 2, 2, 0, &msg) == SPIRA_E_INVALID);
+    s5[5] = 1;
+    double t10[10] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 1}, m8d[8] = {0};
+    CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == 0);
+    t10[4] = NAN; CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == SPIRA_E_INVALID);
+    t10[4] = 0; t10[9] = 0; CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == SPIRA_E_INVALID);
+    CHECK(spira::scene_arrays_check<double>(nullptr, nullptr, nullptr, 0, 1, 0, &msg) == SPIRA_E_INVALID);
+    std::vector<spira::HostPack4<float>> nodes, tris;
+    CHECK(!spira::bvh_build<float>(nullptr, 0, nodes, tris, nullptr));                            // empty
+    CHECK(!spira::bvh_build<float>(nullptr, (1u << 24) + 1, nodes, tris, nullptr));               // over the 2^24 limit: rejected before any read
+}
+
+static void oracle_checks() {   // the checker itself under ASan/UBSan: S2-like scene, all estimators, extensions, tilings, row orders
+    const double sph[25] = {0, -100.5, -1, 100, 1, 0, 0, -1, 0.5, 2, 1, 0, -1, 0.5, 3, -1, 0, -1, 0.5, 4, 0, 2, 0, 0.5, 5};
+    const double mat[48] = {0.8, 0.8, 0.2, 0, 0, 0, 0, 1, 0.8, 0.2, 0.2, 0, 0, 0, 0, 1, 0.8, 0.6, 0.2, 0, 0, 0, 0.8, 0.3, 0.9, 0.9, 0.9, 0, 0, 0, 0, -1.5,
+                            0.8, 0.8, 0.8, 4, 4, 4, 0, 1, 0.2, 0.8, 0.2, 0, 0, 0, 0, 1};
+    const double tri[10] = {-0.5, 0, -2, 0.5, 0, -2, 0, 1, -2, 6};
+    const double cam[12] = {0, 1, 3, -1.4, -0.2, 1.6, 2.9, 0, 0, 0, 1.5, -0.6};
+    std::vector<double> hdr(3 * 23 * 41), img(3 * 23 * 41);
+    uint64_t seg = 0;
+    for (uint32_t flags : {0u, (uint32_t)SPIRA_EXT_DIELECTRIC, (uint32_t)SPIRA_EXT_SPECTRAL, (uint32_t)(SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL | SPIRA_ROWS_BOTTOM_UP | SPIRA_POST_ACES_GAMMA)}) {
+        spira_params p{}; p.width = 41; p.height = 23; p.spp = 3; p.max_depth = 6; p.n_spheres = 5; p.n_materials = 6; p.n_triangles = 1; p.flags = flags; p.seed = 99;
+        CHECK(oracle_render_f64(sph, mat, tri, cam, &p, hdr.data(), img.data(), 2, &seg) == 0 && seg > 41 * 23 * 3);
+        p.rows = 8; p.stripe_h = 4; p.stripe_count = 3; p.stripe_rank = 2;        // rows 8..11, 20..22 (ragged)
+        p.rows = 7;
+        CHECK(oracle_render_f64(sph, mat, tri, cam, &p, hdr.data(), img.data(), 1, &seg) == 0);
+    }
+    float sphf[25], matf[48], camf[12];
+    for (int i = 0; i < 25; ++i) sphf[i] = (float)sph[i];
+    for (int i = 0; i < 48; ++i) matf[i] = (float)std::fabs(mat[i]);
+    for (int i = 0; i < 12; ++i) camf[i] = (float)cam[i];
+    std::vector<float> hf(3 * 23 * 41), imf(3 * 23 * 41);
+    for (uint32_t sem : {(uint32_t)SPIRA_SEM_CPU, (uint32_t)SPIRA_SEM_METAL}) {
+        spira_params p{}; p.width = 41; p.height = 23; p.spp = 4; p.max_depth = 9; p.n_spheres = 5; p.n_materials = 6; p.flags = sem; p.seed = 5;
+        CHECK(oracle_render_variant_f32(sphf, matf, camf, &p, hf.data(), imf.data(), 2, &seg) == 0 && seg > 0);
+    }
+    for (float v : hf) CHECK(std::isfinite(v));
+}
+
+int main() {
+    meshes<float>();
+    meshes<double>();
+    fastdiv_checks();
+    validation_checks();
+    oracle_checks();
+    if (g_fail) { std::fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
+    std::printf("host sanitize harness: all checks passed\n");
+    return 0;
+}

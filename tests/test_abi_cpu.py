@@ -143,3 +143,91 @@ def test_png_writer(tmp_path):
     n = int.from_bytes(blob[i - 4:i], "big")
     raw = zlib.decompress(blob[i + 4:i + 4 + n])
     assert len(raw) == 4 * (1 + 5 * 3) and raw[1 * 16 + 1 + 2 * 3:1 * 16 + 1 + 2 * 3 + 3] == bytes([255, 128, 0])
+
+
+# --------------------------------------------------------------------- julia/SPIRA.jl `ccall`s against the header, argument by argument
+_J2C = {   # Julia ccall type -> the C types it may stand for
+    "Cint": {"int"}, "Cfloat": {"float"}, "Cdouble": {"double"}, "UInt32": {"uint32_t"}, "UInt64": {"uint64_t"},
+    "Cstring": {"const char *"},
+    "Ptr{Float32}": {"const float *", "float *"}, "Ptr{Float64}": {"const double *", "double *"},
+    "Ptr{UInt32}": {"const uint32_t *", "uint32_t *"},
+    "Ref{SpiraParams}": {"const spira_params *"},
+    "Ptr{Cvoid}": {"void *", "spira_scene *", "const spira_scene *"}, "Ptr{Ptr{Cvoid}}": {"spira_scene **"},
+}
+
+
+def _c_prototypes():
+    hdr = open(os.path.join(ROOT, "include", "spira_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"^\s*((?:const\s+)?[a-z_0-9]+\s*\**)\s*(spira_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr, flags=re.M):
+        ctypes_ = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("void", ""):
+                continue
+            m = re.match(r"^(.*?)([A-Za-z_][A-Za-z_0-9]*)?(\[\d*\])?$", a)
+            typ, arr = m.group(1).strip(), m.group(3)
+            if not typ:                       # unnamed parameter (e.g. "uint32_t")
+                typ = m.group(2)
+            if arr:
+                typ += " *"
+            typ = re.sub(r"\s*\*", " *", re.sub(r"\s+", " ", typ)).replace("* *", "**").strip()
+            ctypes_.append(typ)
+        protos[name] = (re.sub(r"\s*\*", " *", re.sub(r"\s+", " ", ret)).strip(), ctypes_)
+    return protos
+
+
+def test_julia_ccalls_match_header_argument_by_argument():
+    src = open(os.path.join(ROOT, "julia-spira_amd", "julia", "SPIRA.jl")).read()
+    src = re.sub(r"#.*", "", src)
+    protos = _c_prototypes()
+    calls = re.findall(r"ccall\(\(:(spira_[a-z0-9_]+),\s*libspira\),\s*([A-Za-z0-9{}]+),\s*\(([^()]*)\)", src)
+    assert len(calls) >= 9
+    seen = set()
+    for name, ret, args in calls:
+        assert name in protos, "SPIRA.jl calls %s, which include/spira_hip.h does not declare" % name
+        cret, cargs = protos[name]
+        assert cret in _J2C[ret], (name, ret, cret)
+        jargs = [a.strip() for a in args.split(",") if a.strip()]
+        assert len(jargs) == len(cargs), (name, jargs, cargs)
+        for k, (ja, ca) in enumerate(zip(jargs, cargs)):
+            assert ca in _J2C[ja], "%s argument %d: Julia %s vs C %s" % (name, k + 1, ja, ca)
+        seen.add(name)
+    assert {"spira_render_f32", "spira_render_scene_f32", "spira_render_multi_f32", "spira_scene_create_f32", "spira_scene_destroy",
+            "spira_camera_lookat_f32", "spira_last_error", "spira_device_count", "spira_set_device"} <= seen
+    # the struct mirror: field order and widths of SpiraParams == spira_params
+    fields = re.search(r"struct SpiraParams(.*?)\nend", src, flags=re.S).group(1)
+    jf = re.findall(r"([a-z_0-9]+)::(UInt32|UInt64)", fields)
+    from spira_hip import _binding
+    assert [(n, {"UInt32": 4, "UInt64": 8}[t]) for n, t in jf] == [(n, C.sizeof(t)) for n, t in _binding.Params._fields_]
+    # flag constants used by the shim
+    hdr = open(os.path.join(ROOT, "include", "spira_hip.h")).read()
+    for const, val in re.findall(r"const (SPIRA_[A-Z_]+)\s*=\s*(0x[0-9a-fA-F]+)", src):
+        m = re.search(r"#define %s\s+(0x[0-9a-fA-F]+)u" % const, hdr)
+        assert m and int(m.group(1), 16) == int(val, 16), const
+
+
+def test_julia_png_and_exr_writers_mirror_the_python_ones(tmp_path):
+    """The Julia file writers cannot run here; their byte layout is the Python writers' (spira_hip/png.py, exr.py), which CAN:
+    PNG with stored deflate blocks decodes back, the EXR header matches the fields the Julia code emits."""
+    import struct
+    import zlib
+    from spira_hip import exr, png
+    rng = np.random.default_rng(0)
+    img = rng.random((5, 7, 3)).astype(np.float32)
+    p = str(tmp_path / "a.png")
+    png.save_png(p, img)
+    blob = open(p, "rb").read()
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n" and b"IHDR" in blob and b"IEND" in blob
+    i = blob.index(b"IDAT")
+    n = struct.unpack(">I", blob[i - 4:i])[0]
+    raw = zlib.decompress(blob[i + 4:i + 4 + n])
+    assert len(raw) == 5 * (1 + 3 * 7)
+    e = str(tmp_path / "a.exr")
+    exr.save_exr(e, img)
+    head = open(e, "rb").read(400)
+    for key in (b"channels\0chlist", b"compression\0compression", b"dataWindow\0box2i", b"lineOrder\0lineOrder", b"screenWindowWidth\0float"):
+        assert key in head
+    src = open(os.path.join(ROOT, "julia-spira_amd", "julia", "SPIRA.jl")).read()
+    for key in ("channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth", "20000630"):
+        assert key in src

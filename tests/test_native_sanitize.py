@@ -1,0 +1,20 @@
+"""CPU: the product's HOST code (BVH builder, scene validation, magic-number division, triangle hash) and the oracle, built into
+one host-only binary with -fsanitize=address,undefined and run over degenerate inputs.  GPU AddressSanitizer is not available
+on the pool; this is where the sanitizers run."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_code_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_sanitize")
+    obj = str(tmp_path / "oracle.o")
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+    subprocess.run(["gcc", "-std=c11", "-ffp-contract=off", "-fopenmp", "-c", os.path.join(ROOT, "oracle", "spira_oracle.c"), "-o", obj] + san, check=True)
+    subprocess.run(["g++", "-std=c++17", "-ffp-contract=off", os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), obj, "-o", exe, "-fopenmp", "-lm"] + san,
+                   check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", OMP_NUM_THREADS="2")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    assert "all checks passed" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
