@@ -797,6 +797,7 @@ template <class T> struct PathArgs {
     uint32_t cap;                    // region size in packets (a multiple of R*64)
     uint32_t pass;
     uint32_t n_first;                // number of paths in this pass
+    uint32_t dense_pct;              // dense continuation threshold in % (0 = always go through the queue)
 };
 
 // queue word C.y: the path index (bit 31 = "L[q] already holds radiance") and, in Float64, the hit reference beside it
@@ -811,6 +812,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
     constexpr bool kRefArray = sizeof(T) == 4;
+    constexpr uint32_t kStageShift = 25, kRefMask = (1u << kStageShift) - 1u;      // a hit reference needs < 2^25; the packet's stage rides above it
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t NW = gridDim.x * WPB, wid = blockIdx.x * WPB + wave;
     const RenderConst<T> &rc = a.rc;
@@ -819,71 +821,95 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     const uint32_t region = wid * a.cap;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t ref_base = sc.n_spheres + sc.n_triangles;     // references >= ref_base are BVH triangle slots
+    // Dense continuation (a.dense_pct > 0, max_depth <= 128): when at least dense_pct % of a sub-chunk's scattered rays hit again, they
+    // stay in registers and go straight into their next stage instead of through the queue — compaction only where it pays (a closed
+    // scene never touches the queues; an open one compacts as before).  Packets then carry their own stage (7 bits above the hit
+    // reference), because a wave's region may hold hits of different segments.
+    const bool mixed = rc.max_depth <= 128u;
+    const uint32_t dense_pct = mixed ? a.dense_pct : 0u;
     uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0;
-    uint32_t n_in = 0;                                           // packets waiting in this wave's region (stages >= 1)
+    uint32_t n_in = 0;                                           // packets waiting in this wave's region (rounds >= 1)
     const uint32_t n_sub_first = (a.n_first + SUB - 1) / SUB;
 
-    for (uint32_t stage = 0; stage < rc.max_depth; ++stage) {
-        const bool first = stage == 0;
-        const bool scatter = stage + 1 < rc.max_depth;
-        const RayQueue<T> qin = a.q[(stage + 1) & 1], qout = a.q[stage & 1];
-        const uint32_t *rin = a.qref[(stage + 1) & 1];
-        uint32_t *rout = a.qref[stage & 1];
+    for (uint32_t round = 0; round < rc.max_depth; ++round) {
+        const bool first = round == 0;
+        const RayQueue<T> qin = a.q[(round + 1) & 1], qout = a.q[round & 1];
+        const uint32_t *rin = a.qref[(round + 1) & 1];
+        uint32_t *rout = a.qref[round & 1];
         const uint32_t limit = first ? a.n_first : n_in;
         const uint32_t n_sub = first ? n_sub_first : (n_in + SUB - 1) / SUB;
         uint32_t fill = 0;
         for (uint32_t sub = first ? wid : 0u; sub < n_sub; sub += first ? NW : 1u) {
             Vec<T> o[R], beta[R];
-            Pending<T> pend[R];
+            Pending<T> pend[R];                           // between trips pend[r].v holds the direction the hit was reached along
             ExtState<T> ex[R];                            // EXT instantiations only (dead otherwise)
-            uint32_t q[R], ent[R];
-            uint32_t n_list = 0;
-            // ---------------- phase 1: the hit of segment `stage`
+            uint32_t q[R], ent[R], stg[R], ref[R];
+            bool valid[R];
+            // ---------------- the sub-chunk's rays: camera rays + their closest hit (round 0) or queued hits
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t idx = sub * SUB + r * 64 + lane;
-                pend[r].kind = kDead;
-                bool want = false;
-                RngKey key;
+                valid[r] = false; stg[r] = round; ref[r] = 0; q[r] = 0;
+                pend[r].kind = kDead; pend[r].rough = 0; pend[r].v = mk<T>(0, 0, 0);
+                o[r] = mk<T>(0, 0, 0); beta[r] = mk<T>(1, 1, 1);
                 if (idx < limit) {
-                    uint32_t pixel, sample, pi, pj;
-                    Vec<T> d;
-                    int prim; uint32_t slot = 0;
                     if (first) {
+                        uint32_t pixel, sample, pi, pj;
+                        Vec<T> d;
                         q[r] = idx;
                         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
                         camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
-                        beta[r] = mk<T>(1, 1, 1);
                         if (EXT) { ex[r].flags = rc.flags; if (rc.flags & kExtSpectral) beta[r] = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]); }
-                        T t;
-                        prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot);      // :335
+                        T t; uint32_t slot;
+                        const int prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot);      // :335
                         ++n_seg;
-                        if (prim >= 0) o[r] = o[r] + d * t;                              // point_at, :138 / :183
+                        if (prim < 0) {                           // the camera ray leaves the scene: sky, :365-366
+                            const Vec<T> c = sky_term_x<T, EXT>(d, beta[r], &ex[r]);
+                            Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
+                            a.L[idx] = l;
+                            ++n_store;
+                        } else {
+                            valid[r] = true;
+                            o[r] = o[r] + d * t;                  // point_at, :138 / :183
+                            ref[r] = (BVH && prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim;
+                            pend[r].v = d;
+                        }
                     } else {
                         const Pack4<T> A = qin.A[region + idx], B = qin.B[region + idx];
                         const Pack2<T> C = qin.C[region + idx];
-                        o[r] = mk<T>(A.x, A.y, A.z);                                     // the hit point
-                        d = mk<T>(A.w, B.x, B.y);
+                        o[r] = mk<T>(A.x, A.y, A.z);              // the hit point
+                        pend[r].v = mk<T>(A.w, B.x, B.y);         // the direction it was reached along
                         beta[r] = mk<T>(B.z, B.w, C.x);
                         q[r] = unpack_q(C.y);
-                        uint32_t ref;
-                        if constexpr (kRefArray) ref = rin[region + idx]; else ref = unpack_ref(C.y);
-                        prim = (int)ref;
-                        if (BVH && ref >= ref_base) { prim = (int)ref_base; slot = ref - ref_base; }
+                        uint32_t w;
+                        if constexpr (kRefArray) w = rin[region + idx]; else w = unpack_ref(C.y);
+                        if (mixed) { stg[r] = w >> kStageShift; ref[r] = w & kRefMask; } else ref[r] = w;
+                        valid[r] = true;
+                    }
+                }
+            }
+            // ---------------- stages on these rays; normally ONE trip, more while the hits stay dense
+            while (true) {
+                uint32_t n_list = 0, n_valid = 0;
+                // ---- phase 1: the hit of segment stg[r]
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    bool want = false;
+                    RngKey key;
+                    const Vec<T> d = pend[r].v;
+                    pend[r].kind = kDead;
+                    if (valid[r]) {
+                        uint32_t pixel = 0, sample = 0, pi, pj;
+                        const bool scatter = stg[r] + 1 < rc.max_depth;
+                        int prim = (int)ref[r]; uint32_t slot = 0;
+                        if (BVH && ref[r] >= ref_base) { prim = (int)ref_base; slot = ref[r] - ref_base; }
+                        const uint32_t qi = q[r] & 0x7FFFFFFFu;
+                        const bool has_l = (q[r] >> 31) != 0;
                         if (EXT) {
-                            path_of<T>(rc, q[r] & 0x7FFFFFFFu, a.pass, pi, pj, pixel, sample);
+                            path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
                             ex[r].flags = rc.flags;
                             if (rc.flags & kExtSpectral) (void)ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]);
                         }
-                    }
-                    const uint32_t qi = q[r] & 0x7FFFFFFFu;
-                    const bool has_l = (q[r] >> 31) != 0;        // only ever set in stages >= 1
-                    if (prim < 0) {                              // (stage 0) the camera ray leaves the scene: sky, :365-366
-                        const Vec<T> c = sky_term_x<T, EXT>(d, beta[r], &ex[r]);
-                        Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
-                        a.L[qi] = l;
-                        ++n_store;
-                    } else {
                         Vec<T> contrib;
                         const bool has_contrib = shade_hit<T, BVH, EXT>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r], &ex[r]);
                         // Path radiance L[q]: while bit 31 of q is clear a term is a plain store (0 + x == x exactly); the
@@ -901,13 +927,13 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         }
                         want = (pend[r].kind == kDiffuse || pend[r].kind == kSpecRough);
                         if (want || (EXT && pend[r].kind == kDielectric)) {
-                            if (!first && !EXT) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
-                            key = rng_key(rc.sA, rc.sB, pixel, sample, stage);
+                            if (!EXT) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
+                            key = rng_key(rc.sA, rc.sB, pixel, sample, stg[r]);
                             if (EXT && pend[r].kind == kDielectric) dielectric_resolve<T>(pend[r], d, key);     // -> kMirror
                         }
                     }
-                }
-                if (scatter) {
+                    const unsigned long long mv = __ballot(pend[r].kind != kDead);
+                    n_valid += (uint32_t)__popcll(mv);
                     const unsigned long long m = __ballot(want);
                     if (want) {                                   // append to the wave's work list
                         ent[r] = n_list + __popcll(m & lt_mask);
@@ -916,83 +942,94 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                     }
                     n_list += (uint32_t)__popcll(m);
                 }
-            }
-            if (!scatter) continue;        // uniform: the last stage only collects emitted radiance
-            wave_lds_sync();
-            // ---------------- phase 2: cooperative random_in_unit_sphere() over the wave's work list
-            {
-                uint32_t e = lane, t = 1, next = 64;
-                bool have = e < n_list;
-                RngKey k; k.hA = 0; k.hB = 0; k.hBr = 0;
-                if (have) {
-                    const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
-                    k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
-                }
-                while (__any(have)) {
-                    bool done = false;
+                if (n_valid == 0) break;           // wave-uniform: nobody scatters (last segments, or an empty tail)
+                wave_lds_sync();
+                // ---- phase 2: cooperative random_in_unit_sphere() over the wave's work list
+                {
+                    uint32_t e = lane, t = 1, next = 64;
+                    bool have = e < n_list;
+                    RngKey k; k.hA = 0; k.hB = 0; k.hBr = 0;
                     if (have) {
-                        T u0, u1, u2;
-                        rng3<T>(k, t, u0, u1, u2, (T)(1.0 / 1048576.0));
-                        Vec<T> c = mk<T>(u0, u1, u2) - mk<T>(1, 1, 1);                   // :311
-                        done = dot(c, c) < (T)1.0;                                      // :312
-                        if (!done && t == kMaxTries) { c = mk<T>(0, 0, 0); done = true; }
-                        if (done) { Pack4<T> w; w.x = c.x; w.y = c.y; w.z = c.z; w.w = 0; s_rnd[e] = w; }
-                        ++t;
+                        const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
+                        k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
                     }
-                    const unsigned long long m = __ballot(done);
-                    if (done) {                                   // take the next unclaimed entry
-                        e = next + __popcll(m & lt_mask); t = 1;
-                        have = e < n_list;
+                    while (__any(have)) {
+                        bool done = false;
                         if (have) {
-                            const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
-                            k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
+                            T u0, u1, u2;
+                            rng3<T>(k, t, u0, u1, u2, (T)(1.0 / 1048576.0));
+                            Vec<T> c = mk<T>(u0, u1, u2) - mk<T>(1, 1, 1);                   // :311
+                            done = dot(c, c) < (T)1.0;                                      // :312
+                            if (!done && t == kMaxTries) { c = mk<T>(0, 0, 0); done = true; }
+                            if (done) { Pack4<T> w; w.x = c.x; w.y = c.y; w.z = c.z; w.w = 0; s_rnd[e] = w; }
+                            ++t;
+                        }
+                        const unsigned long long m = __ballot(done);
+                        if (done) {                                   // take the next unclaimed entry
+                            e = next + __popcll(m & lt_mask); t = 1;
+                            have = e < n_list;
+                            if (have) {
+                                const uint32_t *kw = reinterpret_cast<const uint32_t *>(&s_rnd[e]);
+                                k.hA = kw[0]; k.hB = kw[1]; k.hBr = (k.hB << 16) | (k.hB >> 16);
+                            }
+                        }
+                        next += (uint32_t)__popcll(m);
+                    }
+                }
+                wave_lds_sync();
+                // ---- phase 3: direction, closest hit of segment stg[r] + 1
+                uint32_t n_hit = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    bool hit = false;
+                    if (pend[r].kind != kDead) {
+                        Vec<T> rnd = mk<T>(0, 0, 0);
+                        if (pend[r].kind != kMirror) { const Pack4<T> w = s_rnd[ent[r]]; rnd = mk<T>(w.x, w.y, w.z); }
+                        const Vec<T> nd = segment_back<T>(o[r], pend[r], rnd);
+                        T t; uint32_t slot;
+                        const int prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot);   // :335 of the next level
+                        ++n_seg;
+                        if (prim < 0) {                               // the path leaves the scene: its last term, :365-366
+                            const Vec<T> c = sky_term_x<T, EXT>(nd, beta[r], &ex[r]);
+                            const uint32_t qi = q[r] & 0x7FFFFFFFu;
+                            Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
+                            if (q[r] >> 31) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + c.x; l.y = l0.y + c.y; l.z = l0.z + c.z; ++n_rmw; }
+                            else ++n_store;
+                            a.L[qi] = l;
+                        } else {
+                            hit = true;
+                            o[r] = o[r] + nd * t;                     // point_at, :138 / :183
+                            ref[r] = (BVH && prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim;
+                            pend[r].v = nd;
+                            ++stg[r];
                         }
                     }
-                    next += (uint32_t)__popcll(m);
+                    valid[r] = hit;
+                    n_hit += (uint32_t)__popcll(__ballot(hit));
                 }
-            }
-            wave_lds_sync();
-            // ---------------- phase 3: direction, closest hit of segment stage+1, compaction of the hits
+                wave_lds_sync();      // the list slots are rewritten by the next trip's / sub-chunk's phase 1
+                if (n_hit == 0) break;
+                if (dense_pct && n_hit * 100u >= n_valid * dense_pct) continue;     // dense: the hits stay in registers
+                // ---- compaction of the hits into this wave's region of the out queue
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                bool hit = false;
-                Vec<T> nd = mk<T>(0, 0, 0);
-                uint32_t ref = 0;
-                if (pend[r].kind != kDead) {
-                    Vec<T> rnd = mk<T>(0, 0, 0);
-                    if (pend[r].kind != kMirror) { const Pack4<T> w = s_rnd[ent[r]]; rnd = mk<T>(w.x, w.y, w.z); }
-                    nd = segment_back<T>(o[r], pend[r], rnd);
-                    T t; uint32_t slot;
-                    const int prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot);   // :335 of the next level
-                    ++n_seg;
-                    if (prim < 0) {                               // the path leaves the scene: its last term, :365-366
-                        const Vec<T> c = sky_term_x<T, EXT>(nd, beta[r], &ex[r]);
-                        const uint32_t qi = q[r] & 0x7FFFFFFFu;
-                        Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
-                        if (q[r] >> 31) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + c.x; l.y = l0.y + c.y; l.z = l0.z + c.z; ++n_rmw; }
-                        else ++n_store;
-                        a.L[qi] = l;
-                    } else {
-                        hit = true;
-                        o[r] = o[r] + nd * t;                     // point_at, :138 / :183
-                        ref = (BVH && prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim;
+                for (int r = 0; r < R; ++r) {
+                    const unsigned long long m = __ballot(valid[r]);
+                    if (valid[r]) {
+                        const uint32_t dst = region + fill + __popcll(m & lt_mask);
+                        const Vec<T> nd = pend[r].v;
+                        const uint32_t w = mixed ? (ref[r] | (stg[r] << kStageShift)) : ref[r];
+                        Pack4<T> A, B; Pack2<T> C;
+                        A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = nd.x;
+                        B.x = nd.y; B.y = nd.z; B.z = beta[r].x; B.w = beta[r].y;
+                        C.x = beta[r].z; C.y = pack_qref(q[r], w, (T)0);
+                        qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
+                        if constexpr (kRefArray) rout[dst] = w;
                     }
+                    fill += (uint32_t)__popcll(m);
                 }
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const uint32_t dst = region + fill + __popcll(m & lt_mask);
-                    Pack4<T> A, B; Pack2<T> C;
-                    A.x = o[r].x; A.y = o[r].y; A.z = o[r].z; A.w = nd.x;
-                    B.x = nd.y; B.y = nd.z; B.z = beta[r].x; B.w = beta[r].y;
-                    C.x = beta[r].z; C.y = pack_qref(q[r], ref, (T)0);
-                    qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
-                    if constexpr (kRefArray) rout[dst] = ref;
-                }
-                fill += (uint32_t)__popcll(m);
+                break;
             }
-            wave_lds_sync();      // the list slots are rewritten by the next sub-chunk's phase 1
         }
-        if (!scatter) break;
         n_in = fill;
         n_enq += fill;
         if (n_in == 0) break;              // wave-uniform: every path of this wave has ended
