@@ -81,13 +81,16 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape):
         tj = json.load(open(tfile))
         if tj.get("kernel") == rec["kernel"]:
             rec["traffic"], rec["traffic_source"] = round(tj["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(tfile)
-            if tj.get("valu"):
+            if tj.get("valu") and tj["valu"].get("issue_frac"):
                 v = tj["valu"]
-                rec["valu"] = {"busy_frac": v["busy_frac"], "lane_utilisation": v["lane_utilisation"], "wave_cycle_shares": v.get("wave_cycle_shares"),
-                               "what": "share of all SIMD cycles in which the VALU is executing an instruction of this kernel "
-                                       "(SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), rocprofv3 --pmc)",
+                rec["valu"] = {"issue_frac": v["issue_frac"], "simd_cycles_per_valu_inst": v["simd_cycles_per_valu_inst"],
+                               "modelled_cycles_per_valu_inst": v["modelled_cycles_per_valu_inst"], "lane_utilisation": v["lane_utilisation"],
+                               "wave_cycle_shares": v.get("wave_cycle_shares"),
+                               "what": "VALU-issue roofline of this kernel: PMC instruction counts per class x the SIMD cycles one wave64 instruction "
+                                       "of that class holds the issue port (profiles/microbench/valu_peak.hip), over the SIMD cycles of the "
+                                       "dispatches (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); rocprofv3 --pmc passes of this same command",
                                "source": rec["traffic_source"]}
-                if v["busy_frac"] > rec["frac"]:
+                if v["issue_frac"] > rec["frac"]:
                     rec["bound"] = "valu"
     return rec
 

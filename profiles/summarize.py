@@ -12,6 +12,19 @@ import sys
 from collections import defaultdict
 
 
+# SIMD cycles (at a nominal 2.4 GHz, i.e. a time) one wave64 VALU instruction of a class holds the issue port, measured on MI355X with
+# profiles/microbench/valu_peak.hip (inline-assembly streams of independent instructions, 4 waves per SIMD; profiles/r02_valu_peak.txt).  "other" = what the class
+# counters do not cover: moves, compares, v_cndmask, the v_div_scale / v_div_fmas / v_div_fixup helpers, v_ldexp, readlane ...
+MICROBENCH_CLOCK_GHZ = 2.3
+VALU_COST = {"SQ_INSTS_VALU_FMA_F32": 3.04, "SQ_INSTS_VALU_MUL_F32": 2.72, "SQ_INSTS_VALU_ADD_F32": 2.66, "SQ_INSTS_VALU_TRANS_F32": 8.3,
+             "SQ_INSTS_VALU_INT32": 3.0,      # the integer work is the hash RNG: per mix32 two v_mul_lo_u32 (4.66) and six shifts / xors (2.5)
+             "SQ_INSTS_VALU_CVT": 4.3, "SQ_INSTS_VALU_FMA_F64": 5.37, "SQ_INSTS_VALU_MUL_F64": 4.92, "SQ_INSTS_VALU_ADD_F64": 4.67,
+             "SQ_INSTS_VALU_TRANS_F64": 16.4, "SQ_INSTS_VALU_INT64": 4.5,
+             # not covered by a class counter: in a Float32 kernel v_mov_b32 2.6, v_cmp 4.3, v_cndmask 4.6, v_div_scale/fmas/fixup 4.4;
+             # in a Float64 kernel v_mov_b64 4.4, v_cmp_f64 4.7, the f64 division helpers 4.8, v_ldexp_f64 4.6
+             "other_f32": 3.9, "other_f64": 4.5}
+
+
 def short(name):
     n = name.replace("void ", "").replace("spira::", "")
     return n.split("(")[0][:60]
@@ -42,18 +55,24 @@ def main():
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
     dur = defaultdict(float)
-    for d in sorted(os.listdir(src)):
+    pass_dur = defaultdict(lambda: defaultdict(float))     # per pass directory: summed dispatch durations (ns) per kernel
+    owner = {}
+    for d in sorted(os.listdir(src), key=lambda x: (x != "pmc_sq1", x)):      # pmc_sq1 first: it holds SQ_INSTS_VALU together with GRBM_GUI_ACTIVE
         f = os.path.join(src, d, "pmc_counter_collection.csv")
         if not d.startswith("pmc_") or not os.path.exists(f):
             continue
         seen = set()
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
+            if owner.setdefault((k, r["Counter_Name"]), d) != d:
+                continue                      # a counter collected by several passes is taken from the first one only
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[k][r["Counter_Name"]] += 1
-            if d == "pmc_fetch" and r["Dispatch_Id"] not in seen:
+            if r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"])
-                dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                pass_dur[d][k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                if d == "pmc_fetch":
+                    dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     lines += ["## --pmc passes (sums over all dispatches of the run; one pass per counter group)", ""]
     for k in sorted(agg, key=lambda x: -dur.get(x, 0)):
         if not k.startswith("k_"):
@@ -75,10 +94,10 @@ def main():
             lines.append("- VALU lane utilisation SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) = %.3f" %
                          (c.get("SQ_THREAD_CYCLES_VALU", 0) / max(1.0, 64 * c["SQ_ACTIVE_INST_VALU"])))
             lines.append("- VALU instructions per wave = %.1f" % (c["SQ_INSTS_VALU"] / max(1.0, c["SQ_WAVES"])))
-        if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
-            # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs; SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)
-            lines.append("- VALU busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) = %.3f" %
-                         (c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8)))
+        if c.get("SQ_INSTS_VALU") and c.get("GRBM_GUI_ACTIVE"):
+            # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md); 1024 SIMDs
+            lines.append("- SIMD cycles per VALU wave-instruction = 1024 x (GRBM_GUI_ACTIVE / 8) / SQ_INSTS_VALU = %.2f" %
+                         (1024 * c["GRBM_GUI_ACTIVE"] / 8 / c["SQ_INSTS_VALU"]))
         if "SQ_WAIT_ANY" in c and "SQ_ACTIVE_INST_ANY" in c:
             tot = c["SQ_WAIT_ANY"] + c["SQ_WAIT_INST_ANY"] + c["SQ_ACTIVE_INST_ANY"]
             lines.append("- wave-cycle shares: WAIT_ANY %.2f, WAIT_INST_ANY %.2f, ACTIVE_INST_ANY %.2f" %
@@ -103,7 +122,34 @@ def main():
                "source": os.path.basename(src.rstrip("/"))}
         if tot("SQ_ACTIVE_INST_VALU") and tot("GRBM_GUI_ACTIVE"):
             w = tot("SQ_WAIT_ANY") + tot("SQ_WAIT_INST_ANY") + tot("SQ_ACTIVE_INST_ANY")
-            out["valu"] = {"busy_frac": round(tot("SQ_ACTIVE_INST_VALU") * 4 / (1024 * tot("GRBM_GUI_ACTIVE") / 8), 4),
+            # VALU-issue roofline: class counts x measured issue cost per class, against the SIMD cycles of the same dispatches
+            # The microbenchmark prints times as "cycles at 2.4 GHz"; its dispatches held 2.14-2.43 GHz (GRBM_GUI_ACTIVE / 8 / duration,
+            # profiles/r02_valu_peak.txt), 2.3 on average, so a real cycle count is 0.96 x the printed one.  The capacity is counted in
+            # real cycles too: GRBM_GUI_ACTIVE (summed over the 8 XCDs by rocprofv3) / 8 per SIMD, whatever clock DVFS let the kernel hold.
+            n_inst = tot("SQ_INSTS_VALU")
+            wall_ns = sum(pass_dur["pmc_sq1"][k] for k in ks)        # the pass that counted SQ_INSTS_VALU and GRBM_GUI_ACTIVE
+            simd_cycles = 1024 * tot("GRBM_GUI_ACTIVE") / 8
+            # the class counters come from other passes of the same (deterministic) command: scale them to this pass's dispatch count
+            n_disp = max(1, sum(calls[k].get("SQ_INSTS_VALU", 0) for k in ks))
+            mix, covered, weighted = {}, 0.0, 0.0
+            for cname, cost in VALU_COST.items():
+                if cname.startswith("other"):
+                    continue
+                nd = sum(calls[k].get(cname, 0) for k in ks)
+                if nd:
+                    cnt = tot(cname) * n_disp / nd
+                    mix[cname.replace("SQ_INSTS_VALU_", "").lower()] = round(cnt / n_inst, 4)
+                    covered += cnt
+                    weighted += cnt * cost * MICROBENCH_CLOCK_GHZ / 2.4
+            issue_frac = None
+            if mix:
+                other = VALU_COST["other_f64"] if mix.get("fma_f64", 0) > mix.get("fma_f32", 0) else VALU_COST["other_f32"]
+                weighted += max(0.0, n_inst - covered) * other * MICROBENCH_CLOCK_GHZ / 2.4
+                mix["other"] = round(max(0.0, n_inst - covered) / n_inst, 4)
+                issue_frac = round(weighted / simd_cycles, 4)
+            out["valu"] = {"issue_frac": issue_frac, "simd_cycles_per_valu_inst": round(simd_cycles / n_inst, 3), "effective_clock_GHz": round(tot("GRBM_GUI_ACTIVE") / 8 / max(wall_ns, 1.0), 3),
+                           "modelled_cycles_per_valu_inst": round(weighted / n_inst, 3) if mix else None, "mix": mix or None,
+                           "issue_cost_table": VALU_COST if mix else None,
                            "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / max(1.0, 64 * tot("SQ_ACTIVE_INST_VALU")), 4),
                            "valu_insts_per_launch": tot("SQ_INSTS_VALU") / max(1, sum(calls[k].get("SQ_INSTS_VALU", 0) for k in ks)),
                            "wave_cycle_shares": {"wait_any": round(tot("SQ_WAIT_ANY") / w, 3), "wait_inst_any": round(tot("SQ_WAIT_INST_ANY") / w, 3),
