@@ -312,9 +312,11 @@ __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<
             T sq = sqrt_rn(disc);                              // :125
             T root = (-b - sq) / two_a;                        // :126
             bool ok = !(root < t_min || root > closest);       // :130
-            if (!ok) {
-                root = (-b + sq) / two_a;                      // :127,:131
-                ok = !(root < t_min || root > closest);        // :132
+            // :127,:131-132.  The second root is only worth a division when the first one fell short of t_min: if the first is
+            // beyond `closest`, the second (-b + sq >= -b - sq, same positive divisor, correctly rounded division is monotone) is too.
+            if (!ok && root < t_min) {
+                root = (-b + sq) / two_a;
+                ok = !(root < t_min || root > closest);
             }
             if (ok) { closest = root; prim = (int)s; }         // :137, :252
         }

@@ -231,3 +231,22 @@ def test_julia_png_and_exr_writers_mirror_the_python_ones(tmp_path):
     src = open(os.path.join(ROOT, "julia-spira_amd", "julia", "SPIRA.jl")).read()
     for key in ("channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth", "20000630"):
         assert key in src
+
+
+def test_multi_device_stripe_logic_on_cpu(binding):
+    """The tiling arithmetic of spira_render_multi_* (host side, no GPU): spira_stripe_rows agrees with the Python sharding for every
+    (height, devices, stripe height), and the row mapping k_assemble uses on device 0 — global row y lives at rank (y / h) % n, local
+    row ((y / h) / n) * h + y % h — is the inverse of the ranks' local row order."""
+    from spira_hip import distributed as D
+    for H in (1, 7, 8, 9, 27, 117, 200, 1080):
+        for n in (1, 2, 3, 5, 8):
+            for h in (1, 2, 4, 8):
+                rows = [D.rows_of_rank(H, n, r, h) for r in range(n)] if n > 1 else [list(range(H))]
+                for r in range(n):
+                    assert binding.stripe_rows(H, h, n, r) == len(rows[r]), (H, n, h, r)
+                sr, sl = D.source_of_rows(H, n, h) if n > 1 else (np.zeros(H, int), np.arange(H))
+                for y in range(H):
+                    sq = y // h
+                    rank, local = (sq % n, (sq // n) * h + y % h)
+                    assert (rank, local) == (int(sr[y]), int(sl[y])) and rows[rank][local] == y
+    assert binding.stripe_rows(100, 8, 0, 0) == 0 and binding.stripe_rows(100, 8, 4, 4) == 0     # bad rank / count
