@@ -18,6 +18,8 @@ Prints ONE JSON line on rank 0.
                 whichever fraction is higher.
   stress        the same frame on S3 (closed box: every path runs all 8 segments), N=1 only.
   organisations the round-1 per-bounce organisation and the megakernel on the same workload, N=1 only (informational).
+  estimators    the reference's two other estimators on the same frame (SPIRA_SEM_METAL in wavefront and in one-lane-per-pixel
+                form, SPIRA_SEM_CPU), N=1 only (informational).
   cpu_baseline  the CPU oracle (a port: the Julia reference cannot run here) on the host cores, N=1 only.
 """
 import argparse
@@ -197,10 +199,10 @@ def main():
     samples_per_step = W * H * spp_total
     value = samples_per_step * args.steps / dt / 1e6
 
-    def side_run(scene, kernel, prec, reps=3):
+    def side_run(scene, kernel, prec, reps=3, sem=0):
         """An extra, untimed-region measurement on rank 0: (Msamples/s, ms per step, roofline record)."""
         sc2, counts2 = workload(scene)
-        fl = kflags[kernel] | B.POST_NONE
+        fl = kflags[kernel] | B.POST_NONE | sem
         pp = B.make_params(W, H, spp_total, depth, *counts2, flags=fl, seed=seed, **tile)
         o2 = torch.empty((3, rows, W), dtype=tdt[prec], device="cuda")
         with B.Scene(sc2[0], sc2[1], sc2[2], prec) as h2:
@@ -213,7 +215,19 @@ def main():
             adt = (time.perf_counter() - t1) / reps
         c = B.counters()
         roof = None
-        if kernel == "wavefront":
+        if sem == B.SEM_METAL and kernel == "wavefront":
+            # k_path_metal: packets of 10 values + {hit sphere, LCG state}; per sample and pixel one read-modify-write of the running
+            # sum (4 values each way) and of the LCG state (4 B each way); the rare radiance terms parked in L
+            pb = 4 if prec == "f32" else 8
+            nbytes = 2 * (10 * pb + 8) * c["rays_enqueued"] + c["samples"] * (8 * pb + 8) + 6 * pb * c["radiance_rmw"]
+            kms = max(c["bounce_kernel_ms"], 1e-9)
+            roof = {"bound": "valu", "kernel": "k_path_metal", "achieved": round(nbytes / (kms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(nbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bytes_per_sample": round(nbytes / c["samples"], 2),
+                    "avg_launch_ms": round(kms, 4), "launches": 1, "packets_per_sample": round(c["rays_enqueued"] / c["samples"], 4),
+                    "segments_per_sample": round(c["segments"] / c["samples"], 4), "traffic": None, "valu": None}
+        elif sem:
+            roof = {"segments_per_sample": round(c["segments"] / c["samples"], 4)}
+        elif kernel == "wavefront":
             roof = roofline_record(c, prec, kernel, scene, headline_shape)
         elif kernel == "bounce":     # per-bounce launches are only bracketed on request (it slows the render): one extra, profiled render
             B.render_device(*sc2, B.make_params(W, H, spp_total, depth, *counts2, flags=fl | B.FLAG_PROFILE, seed=seed, **tile),
@@ -240,7 +254,7 @@ def main():
             v, ms, aroof = side_run(scene_name, args.kernel, ap_)
             alt = {"dtype": ap_, "value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": aroof}
         # ---- stress scene and the other kernel organisations (N=1 only; informational)
-        stress, orgs = None, None
+        stress, orgs, estimators = None, None, None
         if world == 1 and not args.no_extras:
             if scene_name != "s3" and args.config != "c5":
                 v, ms, sroof = side_run("s3", args.kernel, args.prec)
@@ -253,6 +267,11 @@ def main():
                     orgs[k] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "dtype": args.prec,
                                "hbm_frac": oroof and oroof["frac"], "bytes_per_sample": oroof and oroof["bytes_per_sample"],
                                "avg_launch_ms": oroof and oroof["avg_launch_ms"], "launches": oroof and oroof["launches"]}
+            if scene_name in ("s1",) and args.config in ("c3", "c4"):        # the reference's other estimators on the same frame (sphere scenes only)
+                estimators = {}
+                for name, sem, k in (("metal_wavefront", B.SEM_METAL, "wavefront"), ("metal_one_lane_per_pixel", B.SEM_METAL, "mega"), ("cpu_one_lane_per_path", B.SEM_CPU, "mega")):
+                    v, ms, eroof = side_run(scene_name, k, args.prec, sem=sem)
+                    estimators[name] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "dtype": args.prec, "roofline": eroof}
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -291,7 +310,7 @@ def main():
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": scene_name, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
-            "roofline": roof, "cpu_baseline": cpu, "other_precision": alt, "stress": stress, "organisations": orgs,
+            "roofline": roof, "cpu_baseline": cpu, "other_precision": alt, "stress": stress, "organisations": orgs, "estimators": estimators,
         }
         print(json.dumps(result), flush=True)
     scene_h.destroy()
