@@ -13,7 +13,18 @@ from spira_hip.png import save_png  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "renders")
 os.makedirs(out, exist_ok=True)
-jobs = [("s1_semA", scenes.scene_s1(), 0, 8), ("s1_semCPU", scenes.scene_s1(), 1, 8), ("s1_semMETAL", scenes.scene_s1(), 2, 8),
+def glass_s2():
+    """S2 with the mirror sphere turned into glass (ior 1.5), the gold one into amber glass (ior 1.33) — SPIRA_EXT_DIELECTRIC."""
+    s = scenes.scene_s2()
+    m = s["materials8"].copy()
+    m[3] = [0.95, 0.95, 0.95, 0, 0, 0, 0.0, -1.5]
+    m[2] = [0.9, 0.7, 0.3, 0, 0, 0, 0.0, -1.33]
+    s["materials8"] = m
+    return s
+
+
+jobs = [("s2_ext_dielectric", glass_s2(), B.EXT_DIELECTRIC, 10), ("s2_ext_dielectric_spectral", glass_s2(), B.EXT_DIELECTRIC | B.EXT_SPECTRAL, 10),
+        ("s1_semA", scenes.scene_s1(), 0, 8), ("s1_semCPU", scenes.scene_s1(), 1, 8), ("s1_semMETAL", scenes.scene_s1(), 2, 8),
         ("s2_semA", scenes.scene_s2(), 0, 8), ("s3_closed_box", scenes.scene_s3(), 0, 8), ("s4_mesh_bvh", scenes.scene_s4(6), 0, 12)]
 for name, s, sem, depth in jobs:
     ns, nm = len(s["spheres5"]), len(s["materials8"])
