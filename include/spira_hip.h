@@ -77,13 +77,15 @@ extern "C" {
 #define SPIRA_SEM_METAL         0x00000002u  /* path_trace src/spira_path_trace_kernel.metal:140-269 */
 /* kernel organisation */
 #define SPIRA_KERNEL_MASK       0x000000F0u
-#define SPIRA_KERNEL_WAVEFRONT  0x00000000u  /* wavefront, default: SoA hit queues, ballot/popcount compaction, ONE persistent
-                                                launch per pass in which every wave walks all bounces on its own queue region */
-#define SPIRA_KERNEL_MEGA       0x00000010u  /* one thread walks one whole path in registers */
+#define SPIRA_KERNEL_DEFAULT    0x00000000u  /* the library's choice = the fastest organisation measured for the estimator:
+                                                SPIRA_SEM_A: WAVEFRONT; SPIRA_SEM_METAL, SPIRA_SEM_CPU: one lane per pixel / path */
+#define SPIRA_KERNEL_MEGA       0x00000010u  /* one lane walks whole paths in registers (with path regeneration) */
 #define SPIRA_KERNEL_BOUNCE     0x00000020u  /* wavefront as in round 1: SoA RAY queues, one launch per bounce (comparison point) */
-/* The organisation applies to SPIRA_SEM_A and, for WAVEFRONT vs the rest, to SPIRA_SEM_METAL (wavefront: every wave owns a block of
- * pixels and walks sample after sample on it, the LCG state travelling in the hit packet; MEGA / BOUNCE: one lane per pixel walks
- * all its samples).  SPIRA_SEM_CPU always runs one lane per path. */
+#define SPIRA_KERNEL_WAVEFRONT  0x00000030u  /* wavefront: SoA hit queues, ballot/popcount compaction, ONE persistent launch per pass in
+                                                which every wave walks all bounces on its own queue region */
+/* The organisation applies to SPIRA_SEM_A and, for WAVEFRONT vs the rest, to SPIRA_SEM_METAL (WAVEFRONT: every wave owns a block of
+ * pixels and walks sample after sample on it, the LCG state travelling in the hit packet; otherwise one lane per pixel walks all its
+ * samples — the faster form for that estimator).  SPIRA_SEM_CPU always runs one lane per path. */
 /* display transform applied to out_img (out_hdr is always the linear mean) */
 #define SPIRA_POST_MASK         0x00000F00u
 #define SPIRA_POST_ACES         0x00000000u  /* clamp(aces(x),0,1)        examples/julia-raytracer.jl:370-384 */

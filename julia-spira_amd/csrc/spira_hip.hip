@@ -167,7 +167,7 @@ int validate_params(const void *camera12, const spira_params *p, uint32_t nt, ui
     if (sem != SPIRA_SEM_A && sem != SPIRA_SEM_CPU && sem != SPIRA_SEM_METAL) return fail(SPIRA_E_UNSUPPORTED, "unknown integrator semantics");
     if (sem != SPIRA_SEM_A && nt) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_CPU / SPIRA_SEM_METAL are sphere-only, like their sources");
     uint32_t kern = p->flags & SPIRA_KERNEL_MASK;
-    if (kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA && kern != SPIRA_KERNEL_BOUNCE) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
+    if (kern != SPIRA_KERNEL_DEFAULT && kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA && kern != SPIRA_KERNEL_BOUNCE) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
     if (p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) {
         if (sem != SPIRA_SEM_A) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_EXT_* extensions apply to SPIRA_SEM_A only");
         if (kern == SPIRA_KERNEL_BOUNCE) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_EXT_* extensions are not built into the per-bounce organisation");

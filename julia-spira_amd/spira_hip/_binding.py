@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SPIRA_HIP_LIB", os.path.join(CSRC, "libspira_hip.so")
 
 # ---- flags (include/spira_hip.h) ----
 SEM_A, SEM_CPU, SEM_METAL = 0x0, 0x1, 0x2
-KERNEL_WAVEFRONT, KERNEL_MEGA, KERNEL_BOUNCE = 0x00, 0x10, 0x20
+KERNEL_DEFAULT, KERNEL_MEGA, KERNEL_BOUNCE, KERNEL_WAVEFRONT = 0x00, 0x10, 0x20, 0x30
 POST_ACES, POST_ACES_GAMMA, POST_CLAMP_GAMMA, POST_NONE = 0x000, 0x100, 0x200, 0x300
 ROWS_BOTTOM_UP = 0x1000
 FLAG_PROFILE = 0x10000
