@@ -45,6 +45,24 @@ def main():
                      "mean": [float(hdr[c].astype(np.float64).mean()) for c in range(3)]}
     json.dump(out, open(os.path.join(HERE, "c2_s1_160x90_spp16_d4.json"), "w"), indent=0)
 
+    # extensions (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL): S2 with two glass spheres, 96x54 spp4 depth8
+    rng = np.random.default_rng(20261005)
+    s = scenes.scene_s2()
+    m = s["materials8"].copy()
+    m[3] = [0.95, 0.95, 0.95, 0, 0, 0, 0.0, -1.5]
+    m[2] = [0.9, 0.7, 0.3, 0, 0, 0, 0.0, -1.33]
+    pixels = [[int(rng.integers(0, 54)), int(rng.integers(0, 96))] for _ in range(192)]
+    out = {"config": "extensions: S2 with glass spheres (ior 1.5 / 1.33), 96x54 spp=4 depth=8", "seed": 77, "pixels": pixels,
+           "materials8": [[float(v) for v in row] for row in m]}
+    for name, flags in (("dielectric", 0x20000), ("spectral", 0x40000), ("both", 0x60000)):
+        p = O.make_params(96, 54, 4, 8, 5, 6, 1, flags=flags | 0x300, seed=77)
+        out[name] = {"flags": flags}
+        for prec in ("f64", "f32"):
+            hdr, _, seg = O.render(s["spheres5"], m, s["triangles10"], s["camera12"], p, prec)
+            out[name][prec] = {"segments": int(seg), "values": [[float(v) for v in hdr[:, y, x]] for y, x in pixels],
+                               "mean": [float(hdr[c].astype(np.float64).mean()) for c in range(3)]}
+    json.dump(out, open(os.path.join(HERE, "ext_s2glass_96x54_spp4_d8.json"), "w"), indent=0)
+
 
 if __name__ == "__main__":
     main()

@@ -98,3 +98,18 @@ def test_extensions_off_change_nothing(oracle):
     x, _, sx = oracle.render(*a, oracle.make_params(40, 22, 3, 5, 5, 6, 1, flags=POST_NONE, seed=9), "f32")
     y, _, sy = oracle.render(*a, oracle.make_params(40, 22, 3, 5, 5, 6, 1, flags=POST_NONE | EXT_DIELECTRIC, seed=9), "f32")   # no negative roughness in S2
     assert np.array_equal(x, y) and sx == sy
+
+
+def test_extension_golden_fixture(oracle):
+    """Regression pin of the extensions' restatement (tests/golden/ext_s2glass_96x54_spp4_d8.json, generated by this oracle — NOT reference
+    output: none exists)."""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "ext_s2glass_96x54_spp4_d8.json")))
+    s = scenes.scene_s2()
+    m = np.array(g["materials8"])
+    for name in ("dielectric", "spectral", "both"):
+        for prec in ("f64", "f32"):
+            hdr, _, seg = oracle.render(s["spheres5"], m, s["triangles10"], s["camera12"],
+                                        oracle.make_params(96, 54, 4, 8, 5, 6, 1, flags=g[name]["flags"] | POST_NONE, seed=g["seed"]), prec)
+            got = np.array([[hdr[c, y, x] for c in range(3)] for y, x in g["pixels"]], dtype=np.float64)
+            assert seg == g[name][prec]["segments"] and np.array_equal(got, np.array(g[name][prec]["values"])), (name, prec)

@@ -85,3 +85,19 @@ def test_ext_off_is_bit_identical_to_default(gpu):
     a, _ = gpu.render(*_args(s), gpu.make_params(160, 90, 5, 6, ns, nm, nt, seed=2), "f32")
     b, _ = gpu.render(*_args(s), gpu.make_params(160, 90, 5, 6, ns, nm, nt, flags=gpu.EXT_DIELECTRIC, seed=2), "f32")
     assert np.array_equal(a, b)
+
+
+def test_ext_golden_fixture_on_gpu(gpu):
+    """The committed extension fixture (oracle-generated regression pin) against the HIP path."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ext_s2glass_96x54_spp4_d8.json")))
+    s = scenes.scene_s2()
+    m = np.array(g["materials8"])
+    for name in ("dielectric", "spectral", "both"):
+        for prec in ("f64", "f32"):
+            hdr, _ = gpu.render(s["spheres5"], m, s["triangles10"], s["camera12"],
+                                gpu.make_params(96, 54, 4, 8, 5, 6, 1, flags=g[name]["flags"] | gpu.POST_NONE, seed=g["seed"]), prec)
+            got = np.array([[hdr[c, y, x] for c in range(3)] for y, x in g["pixels"]], dtype=np.float64)
+            want = np.array(g[name][prec]["values"])
+            assert np.all(np.abs(got - want) <= 1e-6 + 1e-5 * np.abs(want)) and gpu.counters()["segments"] == g[name][prec]["segments"], (name, prec)
