@@ -433,8 +433,9 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
         }
     if (int rc = c.L.ensure(batch * sizeof(spira::Pack3<T>))) return rc;
     if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
-    if (int rc = c.counts.ensure((size_t)(SPIRA_MAX_DEPTH + 2) * G_max * wpb * sizeof(uint32_t))) return rc;
-    if (int rc = c.blkstats.ensure((size_t)(SPIRA_MAX_DEPTH + 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
+    // per-wave survivor counts exist in the per-bounce organisation only; statistics: one row per wave per launch
+    if (per_bounce) { if (int rc = c.counts.ensure((size_t)(p->max_depth + 2) * G_max * wpb * sizeof(uint32_t))) return rc; }
+    if (int rc = c.blkstats.ensure((size_t)(per_bounce ? p->max_depth + 1 : 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
     if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
 
     spira::BounceArgs<T> a{};
