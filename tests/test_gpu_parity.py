@@ -147,6 +147,18 @@ def test_triangles_only_and_no_spheres(gpu, oracle):
     assert _close(hdr, ohdr)[0] == 0
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_empty_scene_is_the_sky(gpu, oracle, prec):
+    """No sphere, no triangle: every camera ray misses; all three organisations, against the oracle."""
+    s = scenes.scene_s1()
+    sph, mats, cam = np.zeros((0, 5)), s["materials8"][:1], s["camera12"]
+    ohdr, _, oseg = oracle.render(sph, mats, None, cam, oracle.make_params(70, 40, 3, 5, 0, 1, 0, seed=4), prec)
+    assert oseg == 70 * 40 * 3
+    for k in (gpu.KERNEL_DEFAULT, gpu.KERNEL_WAVEFRONT, gpu.KERNEL_BOUNCE, gpu.KERNEL_MEGA):
+        hdr, _ = gpu.render(sph, mats, None, cam, gpu.make_params(70, 40, 3, 5, 0, 1, 0, flags=k, seed=4), prec)
+        assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg and gpu.counters()["rays_enqueued"] == 0, k
+
+
 def test_max_depth_zero_is_black(gpu):
     s = scenes.scene_s1()
     hdr, img = gpu.render(*_args(s), gpu.make_params(32, 18, 2, 0, 5, 5, seed=1), "f32", want_img=True)
