@@ -147,6 +147,34 @@ def test_triangles_only_and_no_spheres(gpu, oracle):
     assert _close(hdr, ohdr)[0] == 0
 
 
+def test_dense_continuation_threshold_does_not_change_results(gpu):
+    """k_path keeps a sub-chunk's hits in registers when at least SPIRA_DENSE_PCT % of its scattered rays hit again (default 90), else
+    compacts them into the queue.  With 50 % the queues hold hits of different segments side by side (packets carry their stage), with 0
+    every hit goes through the queue, with 100 only fully dense sub-chunks stay in registers: same pixels, same segment counts."""
+    import os
+    rng = np.random.default_rng(21)
+    cases = [(scenes.scene_s1(), 161, 91, 6, 8), (scenes.scene_s3(), 96, 54, 4, 9), (scenes.scene_s4(level=3), 120, 68, 3, 12), (random_scene(rng, 30, 20), 97, 55, 5, 7)]
+    old = os.environ.get("SPIRA_DENSE_PCT")
+    try:
+        for s, W, H, spp, depth in cases:
+            ns, nm, nt = _counts(s)
+            ref, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.KERNEL_MEGA, seed=3), "f32")
+            seg = gpu.counters()["segments"]
+            enq = {}
+            for pct in ("0", "50", "90", "100"):
+                os.environ["SPIRA_DENSE_PCT"] = pct
+                got, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.KERNEL_WAVEFRONT, seed=3, batch_rays=30000), "f32")
+                c = gpu.counters()
+                assert np.array_equal(ref, got) and c["segments"] == seg, pct
+                enq[pct] = c["rays_enqueued"]
+            assert enq["0"] >= enq["50"] >= enq["100"] and enq["0"] > enq["50"]          # the threshold really moves packets out of the queues
+    finally:
+        if old is None:
+            os.environ.pop("SPIRA_DENSE_PCT", None)
+        else:
+            os.environ["SPIRA_DENSE_PCT"] = old
+
+
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_empty_scene_is_the_sky(gpu, oracle, prec):
     """No sphere, no triangle: every camera ray misses; all three organisations, against the oracle."""
