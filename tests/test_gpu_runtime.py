@@ -68,6 +68,24 @@ def test_scene_handle_equals_arrays_and_is_reusable(gpu):
         gpu.Scene(bad, s["materials8"], None, "f32")
 
 
+def test_scene_handle_device_output_on_a_side_stream(gpu):
+    """spira_render_scene_device_*: a handle, device outputs, the caller's stream (what bench.py's timed loop does)."""
+    import torch
+    s = scenes.scene_s3()
+    ns, nm, nt = _counts(s)
+    for prec, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+        p = gpu.make_params(192, 108, 6, 8, ns, nm, nt, flags=gpu.POST_ACES_GAMMA, seed=8)
+        hdr, img = gpu.render(*_args(s), p, prec, want_img=True)
+        st = torch.cuda.Stream()
+        d_hdr = torch.empty((3, 108, 192), dtype=tdt, device="cuda:0")
+        d_img = torch.empty((3, 108, 192), dtype=tdt, device="cuda:0")
+        with gpu.Scene(s["spheres5"], s["materials8"], s["triangles10"], prec) as sc:
+            for _ in range(3):
+                sc.render_device(s["camera12"], p, d_hdr.data_ptr(), d_img.data_ptr(), st.cuda_stream)
+            st.synchronize()
+        assert np.array_equal(d_hdr.cpu().numpy(), hdr) and np.array_equal(d_img.cpu().numpy(), img)
+
+
 def test_scene_handle_removes_per_frame_host_work(gpu):
     """Config-5 mesh (81 920 triangles): per-call host time of the array entry point (re-validates every material index and
     hashes 3.3 / 6.5 MB of triangles to find the cached tree) against a handle.  Reported, and the handle must not be slower."""
