@@ -823,7 +823,8 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     const uint32_t region = wid * a.cap;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t ref_base = sc.n_spheres + sc.n_triangles;     // references >= ref_base are BVH triangle slots
-    // Dense continuation (a.dense_pct > 0, max_depth <= 128): when at least dense_pct % of a sub-chunk's scattered rays hit again, they
+    // Dense continuation (a.dense_pct > 0, max_depth <= 128; host default 80 % in Float64, 90 % in Float32): when at least dense_pct % of a
+    // sub-chunk's scattered rays hit again, they
     // stay in registers and go straight into their next stage instead of through the queue — compaction only where it pays (a closed
     // scene never touches the queues; an open one compacts as before).  Packets then carry their own stage (7 bits above the hit
     // reference), because a wave's region may hold hits of different segments.
