@@ -389,6 +389,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     uint32_t target = p->batch_rays ? p->batch_rays : env_u32("SPIRA_BATCH_RAYS", 160u << 20);
     uint64_t slots64 = std::max<uint64_t>(1, target / tile_pixels);
     slots64 = std::min<uint64_t>(slots64, p->spp);
+    slots64 = (p->spp + (p->spp + slots64 - 1) / slots64 - 1) / ((p->spp + slots64 - 1) / slots64);      // equal passes: spp 256 at 80 slots -> 4 x 64, not 3 x 80 + 16
     if (slots64 * tile_pixels > 0x7FFFFFFFull) return fail(SPIRA_E_LIMIT, "tile too large: rows*width must be < 2^31");
     const uint32_t slots = (uint32_t)slots64;
     const uint64_t batch = slots64 * tile_pixels;
