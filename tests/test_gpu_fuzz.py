@@ -1,5 +1,5 @@
 """GPU (MI355X): seeded fuzz of the C ABI against the oracle — random image sizes, spp, depth, tilings, batch sizes,
-kernel organisations, precisions, estimators and scenes (spheres, LDS triangles, BVH meshes).  Every case: image within
+kernel organisations, precisions, estimators, the two extensions and scenes (spheres, LDS triangles, BVH meshes).  Every case: image within
 the north-star tolerance of the oracle and identical segment counts."""
 import os
 
@@ -42,7 +42,15 @@ def test_fuzz_against_oracle(gpu, oracle):
         sem = 0
         if nt == 0 and rng.random() < 0.3:
             sem = int(rng.choice([1, 2]))
-        kflag = (gpu.KERNEL_WAVEFRONT, gpu.KERNEL_WAVEFRONT, gpu.KERNEL_BOUNCE, gpu.KERNEL_MEGA)[int(rng.integers(0, 4))]
+        kflag = (gpu.KERNEL_DEFAULT, gpu.KERNEL_WAVEFRONT, gpu.KERNEL_BOUNCE, gpu.KERNEL_MEGA)[int(rng.integers(0, 4))]
+        ext = 0
+        if sem == 0 and kflag != gpu.KERNEL_BOUNCE and rng.random() < 0.3:        # the extensions: some materials become glass, and / or spectral transport
+            ext = int(rng.choice([gpu.EXT_DIELECTRIC, gpu.EXT_SPECTRAL, gpu.EXT_DIELECTRIC | gpu.EXT_SPECTRAL]))
+            if ext & gpu.EXT_DIELECTRIC:
+                m = s["materials8"].copy()
+                glass = rng.random(len(m)) < 0.4
+                m[glass, 7] = -rng.uniform(1.05, 2.4, int(glass.sum())).astype(np.float32).astype(np.float64)
+                s = dict(s, materials8=m)
         seed = int(rng.integers(0, 2 ** 40))
         batch = int(rng.choice([0, 1, W * H * 2 + 3, 1 << 20]))
         tile = {}
@@ -51,7 +59,7 @@ def test_fuzz_against_oracle(gpu, oracle):
             tile = D.tile_params(H, world, int(rng.integers(0, world)), int(rng.integers(1, 9)))
             if tile["rows"] == 0:
                 tile = {}
-        flags = sem | kflag | gpu.POST_NONE
+        flags = sem | kflag | ext | gpu.POST_NONE
         hdr, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=flags, seed=seed, batch_rays=batch, **tile), prec)
         po = oracle.make_params(W, H, spp, depth, ns, nm, nt, flags=flags, seed=seed, **tile)
         if sem == 0:
