@@ -10,7 +10,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-BENCH="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-precision --no-extras $*"
+# 4 warm-up + 8 timed steps: the first launches of a process run slower (first touch of 25 GB of workspaces, clocks ramping)
+BENCH="bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-alt-precision --no-extras $*"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 $BENCH > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

@@ -52,6 +52,14 @@ def main():
                 cnt_b += int(r["Calls"])
         if cnt_b:
             lines += ["", "dominant kernel (k_path / k_bounce, all instantiations): %d launches, average %.2f us" % (cnt_b, tot_b / cnt_b / 1e3), ""]
+    kt = os.path.join(src, "trace", "trace_kernel_trace.csv")
+    if os.path.exists(kt):       # launch by launch: the first launches of a process are slower than the steady state bench.py times
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt)) if "k_path" in r["Kernel_Name"]]
+        if len(d) >= 4:
+            half = d[len(d) // 2:]
+            lines += ["k_path launch by launch (us): " + ", ".join("%.0f" % x for x in d),
+                      "steady state (mean of the last %d launches): %.2f us — compare `roofline.avg_launch_ms` of the bench line above (HIP events around the last timed step's launch)" %
+                      (len(half), sum(half) / len(half)), ""]
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(lambda: defaultdict(int))
     dur = defaultdict(float)
