@@ -100,8 +100,8 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps first: the first ~6 launches of a process run up to 20 %% slower (profiles/r02_s1_f64.md)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="BASELINE.json configuration (c3 = configs[2], the headline)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
