@@ -199,14 +199,15 @@ def main():
     samples_per_step = W * H * spp_total
     value = samples_per_step * args.steps / dt / 1e6
 
-    def side_run(scene, kernel, prec, reps=3, sem=0):
+    def side_run(scene, kernel, prec, reps=5, sem=0):
         """An extra, untimed-region measurement on rank 0: (Msamples/s, ms per step, roofline record)."""
         sc2, counts2 = workload(scene)
         fl = kflags[kernel] | B.POST_NONE | sem
         pp = B.make_params(W, H, spp_total, depth, *counts2, flags=fl, seed=seed, **tile)
         o2 = torch.empty((3, rows, W), dtype=tdt[prec], device="cuda")
         with B.Scene(sc2[0], sc2[1], sc2[2], prec) as h2:
-            h2.render_device(sc2[3], pp, o2.data_ptr(), 0, stream.cuda_stream)
+            for _ in range(3):                 # warm-up: a configuration's first launches run slower (profiles/r02_*.md)
+                h2.render_device(sc2[3], pp, o2.data_ptr(), 0, stream.cuda_stream)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(reps):
