@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
@@ -836,37 +837,60 @@ int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
     const int caller_device = tl_device;
+    // Every device finishes (or fails) its allocation + render-enqueue phase before any of them enters the exchange: a device that
+    // failed early must not leave device 0 waiting on the stream for a tile that will never be sent.
+    std::mutex gate_mu;
+    std::condition_variable gate_cv;
+    uint32_t gate_arrived = 0;
+    bool gate_failed = false;
+    auto gate = [&](bool ok) -> bool {        // returns whether ALL devices got here without an error
+        std::unique_lock<std::mutex> lk(gate_mu);
+        if (!ok) gate_failed = true;
+        if (++gate_arrived == n) gate_cv.notify_all();
+        else gate_cv.wait(lk, [&] { return gate_arrived == n; });
+        return !gate_failed;
+    };
     auto worker = [&](uint32_t r) {
         tl_device = rehearse ? 0 : (int)r;
         auto bail = [&](int rc) { rcs[r] = rc; errs[r] = tl_err; };
         Ctx *cp = nullptr;
-        if (int rc = get_ctx(&cp)) return bail(rc);
-        Ctx &c = *cp;
-        hipStream_t st = c.stream;
-        {
-            std::lock_guard<std::mutex> lock(c.mu);
-            if (int rc = c.multi_tile.ensure(2 * tile_elems * sizeof(T))) return bail(rc);      // the tile + a scratch copy for ragged tiles
-            if (r == 0 || rehearse) {
-                if (int rc = c.multi_stack.ensure((size_t)n * tile_elems * sizeof(T))) return bail(rc);
-                if (int rc = c.multi_full.ensure((size_t)6 * H * W * sizeof(T))) return bail(rc);
+        hipStream_t st = nullptr;
+        const uint32_t rows_r_all = (n == 1) ? H : stripe_rows(H, kMultiStripeH, n, r);
+        auto phase1 = [&]() -> int {          // workspaces + this device's tile, enqueued on its stream
+            if (int rc = get_ctx(&cp)) return rc;
+            Ctx &c = *cp;
+            st = c.stream;
+            {
+                std::lock_guard<std::mutex> lock(c.mu);
+                if (int rc = c.multi_tile.ensure(2 * tile_elems * sizeof(T))) return rc;      // the tile + a scratch copy for ragged tiles
+                if (r == 0 || rehearse) {
+                    if (int rc = c.multi_stack.ensure((size_t)n * tile_elems * sizeof(T))) return rc;
+                    if (int rc = c.multi_full.ensure((size_t)6 * H * W * sizeof(T))) return rc;
+                }
             }
-        }
-        spira_params tp = *p;
-        tp.rows = stripe_rows(H, kMultiStripeH, n, r);
-        tp.row0 = 0; tp.stripe_h = kMultiStripeH; tp.stripe_count = n; tp.stripe_rank = r;
-        if (n == 1) { tp.rows = 0; tp.stripe_h = 0; tp.stripe_count = 0; tp.stripe_rank = 0; }
-        T *d_hdr = (T *)c.multi_tile.p, *d_img = d_hdr + (size_t)3 * max_rows * W;
-        // render_impl writes each output as [3][rows][W] contiguously; the gather wants every tile at the pitch of the largest one
-        // ([6][max_rows][W]).  A tile with fewer rows (ragged last stripes) is rendered into the second half of the buffer and its
-        // six planes are re-pitched with one strided device copy.
-        const uint32_t rows_r = (n == 1) ? H : tp.rows;
-        if (rows_r != max_rows) {
-            T *scratch = d_hdr + tile_elems;
-            if (int rc = render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, scratch, scratch + (size_t)3 * rows_r * W, true, st)) return bail(rc);
-            hipError_t e = hipMemcpy2DAsync(d_hdr, (size_t)max_rows * W * sizeof(T), scratch, (size_t)rows_r * W * sizeof(T), (size_t)rows_r * W * sizeof(T), 6,
-                                            hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) { tl_err = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e); return bail(SPIRA_E_HIP); }
-        } else if (int rc = render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, d_hdr, d_img, true, st)) return bail(rc);
+            spira_params tp = *p;
+            tp.rows = rows_r_all;
+            tp.row0 = 0; tp.stripe_h = kMultiStripeH; tp.stripe_count = n; tp.stripe_rank = r;
+            if (n == 1) { tp.rows = 0; tp.stripe_h = 0; tp.stripe_count = 0; tp.stripe_rank = 0; }
+            T *d_hdr = (T *)c.multi_tile.p, *d_img = d_hdr + (size_t)3 * max_rows * W;
+            // render_impl writes each output as [3][rows][W] contiguously; the gather wants every tile at the pitch of the largest one
+            // ([6][max_rows][W]).  A tile with fewer rows (ragged last stripes) is rendered into the second half of the buffer and its
+            // six planes are re-pitched with one strided device copy.
+            if (rows_r_all != max_rows) {
+                T *scratch = d_hdr + tile_elems;
+                if (int rc = render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, scratch, scratch + (size_t)3 * rows_r_all * W, true, st)) return rc;
+                hipError_t e = hipMemcpy2DAsync(d_hdr, (size_t)max_rows * W * sizeof(T), scratch, (size_t)rows_r_all * W * sizeof(T), (size_t)rows_r_all * W * sizeof(T), 6,
+                                                hipMemcpyDeviceToDevice, st);
+                if (e != hipSuccess) return fail(SPIRA_E_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e));
+                return 0;
+            }
+            return render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, d_hdr, d_img, true, st);
+        };
+        const int rc1 = phase1();
+        if (rc1) bail(rc1);
+        if (!rehearse) { if (!gate(rc1 == 0)) { if (st) (void)hipStreamSynchronize(st); return; } }
+        else if (rc1) return;
+        Ctx &c = *cp;
         // ---- the one exchange of the path: every tile to device 0 (RCCL point-to-point over xGMI; n-1 transfers arrive at once)
         if (rehearse) {
             hipError_t he = hipMemcpyAsync((T *)c.multi_stack.p + (size_t)r * tile_elems, c.multi_tile.p, tile_elems * sizeof(T), hipMemcpyDeviceToDevice, st);
