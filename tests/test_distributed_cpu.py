@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, stripe_h, out_path):
+def _worker(rank, world, port, stripe_h, out_path, force_mode=None):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path[:0] = [os.path.join(root, "julia-spira_amd"), os.path.join(root, "oracle")]
@@ -31,6 +31,8 @@ def _worker(rank, world, port, stripe_h, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if force_mode:        # the branch taken for gloo with device tensors (one-GPU rehearsal), exercised here on CPU tensors
+        D.collective_mode = lambda backend, device_type: force_mode
     s = scenes.scene_s2()
     tp = D.tile_params(H, world, rank, stripe_h)
     p = O.make_params(W, H, SPP, DEPTH, 5, 6, 1, seed=SEED, **tp)
@@ -52,6 +54,20 @@ def test_two_rank_stripes_equal_full(tmp_path, oracle):
         out = str(tmp_path / ("img_%d.npy" % stripe_h))
         mp.spawn(_worker, args=(2, _free_port(), stripe_h, out), nprocs=2, join=True)
         assert np.array_equal(np.load(out), full)
+
+
+def test_two_rank_all_gather_branch(tmp_path, oracle):
+    s = scenes.scene_s2()
+    full, _, _ = oracle.render(s["spheres5"], s["materials8"], s["triangles10"], s["camera12"],
+                               oracle.make_params(W, H, SPP, DEPTH, 5, 6, 1, seed=SEED), "f32")
+    out = str(tmp_path / "img_ag.npy")
+    mp.spawn(_worker, args=(2, _free_port(), 8, out, "all_gather"), nprocs=2, join=True)
+    assert np.array_equal(np.load(out), full)
+
+
+def test_collective_is_chosen_from_shared_facts_only():
+    assert D.collective_mode("nccl", "cuda") == "gather" and D.collective_mode("gloo", "cpu") == "gather"
+    assert D.collective_mode("gloo", "cuda") == "all_gather"
 
 
 def test_assemble_numpy():
