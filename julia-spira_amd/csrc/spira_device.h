@@ -104,6 +104,8 @@ template <class T> struct SceneLds {
     const Pack4<T> *bvh_nodes;
     const Pack4<T> *bvh_tris;
     uint32_t n_bvh_tris;
+    const Pack4<T> *bvh_root;   // LDS: {min, max} of the whole mesh (union of the root's two padded child boxes): a ray that misses it
+                                // never touches the tree in global memory
     const T *spd;           // SPIRA_EXT_SPECTRAL: kSpdRows x kSpdN table (include/spira_spd.h) staged behind the scene, else unused
 };
 
@@ -121,11 +123,20 @@ template <class T> struct SceneGlobal {     // flat arrays exactly as passed thr
     const T *spd;           // device copy of the SPD table, or NULL (extension off)
 };
 
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // box tests only (conservative)
+__device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
+__device__ __forceinline__ float min_nn(float a, float b) { return __builtin_fminf(a, b); }  // NaN-ignoring
+__device__ __forceinline__ float max_nn(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double min_nn(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double max_nn(double a, double b) { return __builtin_fmax(a, b); }
+
 template <class T> __host__ __device__ inline size_t scene_lds_bytes(uint32_t ns, uint32_t nm, uint32_t nt) {
     size_t b = (size_t)ns * sizeof(Pack4<T>) + (size_t)nt * 3 * sizeof(Pack4<T>) + (size_t)nm * 2 * sizeof(Pack4<T>);
     b += ((size_t)ns + nt) * sizeof(int);
     b = (b + 31) & ~(size_t)31;
     b += (size_t)kSpdRows * kSpdN * sizeof(T);        // the SPD table's slot (1.7 KB in Float64; filled only in spectral mode)
+    b = (b + 31) & ~(size_t)31;
+    b += 2 * sizeof(Pack4<T>);                        // the mesh's bounding box (BVH scenes)
     return (b + 31) & ~(size_t)31;
 }
 
@@ -167,12 +178,21 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
     T *spd = reinterpret_cast<T *>(lds + spd_off);
     if (g.spd)
         for (uint32_t i = threadIdx.x; i < (uint32_t)(kSpdRows * kSpdN); i += blockDim.x) spd[i] = g.spd[i];
+    Pack4<T> *root = reinterpret_cast<Pack4<T> *>(lds + ((spd_off + (size_t)kSpdRows * kSpdN * sizeof(T) + 31) & ~(size_t)31));
+    if (g.n_bvh_tris && threadIdx.x == 0) {            // union of the root node's two child boxes (an absent child's box is inverted: +inf / -inf)
+        const Pack4<T> l0 = g.bvh_nodes[0], l1 = g.bvh_nodes[1], r0 = g.bvh_nodes[2], r1 = g.bvh_nodes[3];
+        Pack4<T> mn, mx;
+        mn.x = min_nn(l0.x, r0.x); mn.y = min_nn(l0.y, r0.y); mn.z = min_nn(l0.z, r0.z); mn.w = 0;
+        mx.x = max_nn(l1.x, r1.x); mx.y = max_nn(l1.y, r1.y); mx.z = max_nn(l1.z, r1.z); mx.w = 0;
+        root[0] = mn; root[1] = mx;
+    }
     __syncthreads();
     SceneLds<T> sc;
     sc.sph = sph; sc.tri = tri; sc.mat = mat; sc.smat = smat; sc.tmat = tmat;
     sc.n_spheres = g.n_spheres; sc.n_triangles = g.n_triangles;
     sc.bvh_nodes = g.bvh_nodes; sc.bvh_tris = g.bvh_tris; sc.n_bvh_tris = g.n_bvh_tris;
     sc.spd = spd;
+    sc.bvh_root = root;
     return sc;
 }
 
@@ -224,12 +244,6 @@ __device__ __forceinline__ bool triangle_test(const Pack4<T> v0, const Pack4<T> 
     return true;
 }
 
-__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // box tests only (conservative)
-__device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
-__device__ __forceinline__ float min_nn(float a, float b) { return __builtin_fminf(a, b); }  // NaN-ignoring
-__device__ __forceinline__ float max_nn(float a, float b) { return __builtin_fmaxf(a, b); }
-__device__ __forceinline__ double min_nn(double a, double b) { return __builtin_fmin(a, b); }
-__device__ __forceinline__ double max_nn(double a, double b) { return __builtin_fmax(a, b); }
 
 constexpr uint32_t kBvhLeafFlagD = 0x80000000u, kBvhNoneD = 0xFFFFFFFFu;
 constexpr int kBvhStackD = 64;
@@ -252,6 +266,9 @@ __device__ __forceinline__ T box_entry(const Pack4<T> mn, const Pack4<T> mx, Vec
 template <class T>
 __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, uint32_t &slot) {
     const Vec<T> inv = mk<T>(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
+    // most rays of a frame never come near the mesh: its bounding box sits in LDS, and a ray that misses it (same conservative slab
+    // test as for the nodes) is done without a single global-memory access
+    if (box_entry<T>(sc.bvh_root[0], sc.bvh_root[1], o, inv, closest) < (T)0) return;
     uint32_t stack[kBvhStackD];
     int sp = 0;
     uint32_t ref = 0;                                          // root: interior node 0
