@@ -307,10 +307,11 @@ __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o,
 // Linear scan with a shrinking t_max, examples/julia-raytracer.jl:242-258; spheres :113-142, triangles
 // :145-187 (LDS-resident), then the BVH for large meshes.  Returns the object index (spheres first, then
 // triangles in the caller's order) or -1.
-template <class T, bool BVH>
-__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit, uint32_t &slot) {
-    T closest = (T)INFINITY;                                   // t_max = Inf, :335
-    int prim = -1;
+// The LDS-resident part of the scan (spheres, then the small triangle set); `closest` / `prim` come in as "nothing yet" and go out updated.
+template <class T>
+__device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim) {
+    closest = (T)INFINITY;                                     // t_max = Inf, :335
+    prim = -1;
     const T a = dot(d, d);                                     // :115 (same value for every sphere)
     const T two_a = (T)2.0 * a;
     const T four_a = (T)4 * a;
@@ -351,6 +352,19 @@ __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<
             }
         }
     }
+}
+
+// Does the ray come near the mesh at all (its LDS-resident bounding box, conservative slab test, within the closest hit so far)?
+template <class T>
+__device__ __forceinline__ bool mesh_box_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T closest) {
+    const Vec<T> inv = mk<T>(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
+    return box_entry<T>(sc.bvh_root[0], sc.bvh_root[1], o, inv, closest) >= (T)0;
+}
+
+template <class T, bool BVH>
+__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit, uint32_t &slot) {
+    T closest; int prim;
+    closest_hit_local<T>(sc, o, d, t_min, closest, prim);
     slot = 0;
     if (BVH) bvh_closest_hit<T>(sc, o, d, t_min, closest, prim, slot);
     t_hit = closest;
@@ -817,6 +831,8 @@ template <class T> struct PathArgs {
     uint32_t pass;
     uint32_t n_first;                // number of paths in this pass
     uint32_t dense_pct;              // dense continuation threshold in % (0 = always go through the queue)
+    Pack4<T> *mesh_list;             // BVH scenes: per wave `cap` entries of 3 packets — rays that reach the mesh's bounding box wait here
+                                     // for the end of the round and are traversed as dense batches of 64 (NULL = traverse in place)
 };
 
 // queue word C.y: the path index (bit 31 = "L[q] already holds radiance") and, in Float64, the hit reference beside it
@@ -847,12 +863,28 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     // reference), because a wave's region may hold hits of different segments.
     const bool mixed = rc.max_depth <= 128u;
     const uint32_t dense_pct = mixed ? a.dense_pct : 0u;
+    // Deferred mesh traversal (BVH scenes, max_depth <= 128): a ray that reaches the mesh's bounding box is not traversed where it
+    // stands — a few lanes of every wave would walk the tree in global memory while the others wait — but parked on the wave's
+    // mesh list and traversed at the end of the round in dense batches of 64; a hit then enters the out queue as a packet of its
+    // own stage.  (On the 81 920-triangle scene of config 5 the in-place traversal was 70 % of the frame time.)
+    const bool defer = BVH && mixed && a.mesh_list != nullptr;
+    Pack4<T> *mlist = a.mesh_list + 3 * (size_t)region;
     uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0;
     uint32_t n_in = 0;                                           // packets waiting in this wave's region (rounds >= 1)
     const uint32_t n_sub_first = (a.n_first + SUB - 1) / SUB;
 
-    for (uint32_t round = 0; round < rc.max_depth; ++round) {
+    // park a ray on the wave's mesh list (entry = 3 packets: {o, d.x} {d.y, d.z, beta.xy} {beta.z, closest so far, q, object so far + stage of the hit})
+    auto park = [&](uint32_t slot_i, const Vec<T> o_, const Vec<T> d_, const Vec<T> beta_, T closest_, uint32_t q_, int prim_, uint32_t stage_hit) {
+        Pack4<T> A, B, C;
+        A.x = o_.x; A.y = o_.y; A.z = o_.z; A.w = d_.x;
+        B.x = d_.y; B.y = d_.z; B.z = beta_.x; B.w = beta_.y;
+        C.x = beta_.z; C.y = closest_; C.z = Bits<T>::from_u32(q_); C.w = Bits<T>::from_u32((uint32_t)(prim_ + 1) | (stage_hit << kStageShift));
+        mlist[3 * (size_t)slot_i] = A; mlist[3 * (size_t)slot_i + 1] = B; mlist[3 * (size_t)slot_i + 2] = C;
+    };
+    const uint32_t n_rounds = defer ? rc.max_depth + 1 : rc.max_depth;      // a parked camera ray is shaded one round later
+    for (uint32_t round = 0; round < n_rounds; ++round) {
         const bool first = round == 0;
+        uint32_t mfill = 0;                                          // entries on the mesh list this round
         const RayQueue<T> qin = a.q[(round + 1) & 1], qout = a.q[round & 1];
         const uint32_t *rin = a.qref[(round + 1) & 1];
         uint32_t *rout = a.qref[round & 1];
@@ -872,6 +904,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                 valid[r] = false; stg[r] = round; ref[r] = 0; q[r] = 0;
                 pend[r].kind = kDead; pend[r].rough = 0; pend[r].v = mk<T>(0, 0, 0);
                 o[r] = mk<T>(0, 0, 0); beta[r] = mk<T>(1, 1, 1);
+                bool parked = false; T park_t = 0; int park_prim = -1;
                 if (idx < limit) {
                     if (first) {
                         uint32_t pixel, sample, pi, pj;
@@ -880,10 +913,15 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
                         camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
                         if (EXT) { ex[r].flags = rc.flags; if (rc.flags & kExtSpectral) beta[r] = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]); }
-                        T t; uint32_t slot;
-                        const int prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot);      // :335
+                        T t; uint32_t slot = 0;
+                        int prim;
+                        if (defer) {
+                            closest_hit_local<T>(sc, o[r], d, (T)0.001, t, prim);                   // :335, spheres and LDS triangles
+                            parked = mesh_box_hit<T>(sc, o[r], d, t);
+                        } else prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot);          // :335
                         ++n_seg;
-                        if (prim < 0) {                           // the camera ray leaves the scene: sky, :365-366
+                        if (parked) { park_t = t; park_prim = prim; pend[r].v = d; }          // parked below, in uniform control flow
+                        else if (prim < 0) {                      // the camera ray leaves the scene: sky, :365-366
                             const Vec<T> c = sky_term_x<T, EXT>(d, beta[r], &ex[r]);
                             Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
                             a.L[idx] = l;
@@ -906,6 +944,11 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         if (mixed) { stg[r] = w >> kStageShift; ref[r] = w & kRefMask; } else ref[r] = w;
                         valid[r] = true;
                     }
+                }
+                if (defer && first) {                             // camera rays that reach the mesh's box: onto the mesh list (stage of the hit: 0)
+                    const unsigned long long mp = __ballot(parked);
+                    if (parked) park(mfill + __popcll(mp & lt_mask), o[r], pend[r].v, beta[r], park_t, q[r], park_prim, 0u);
+                    mfill += (uint32_t)__popcll(mp);
                 }
             }
             // ---------------- stages on these rays; normally ONE trip, more while the hits stay dense
@@ -1001,15 +1044,21 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                 uint32_t n_hit = 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    bool hit = false;
+                    bool hit = false, parked3 = false;
+                    T park_t3 = 0; int park_prim3 = -1;
                     if (pend[r].kind != kDead) {
                         Vec<T> rnd = mk<T>(0, 0, 0);
                         if (pend[r].kind != kMirror) { const Pack4<T> w = s_rnd[ent[r]]; rnd = mk<T>(w.x, w.y, w.z); }
                         const Vec<T> nd = segment_back<T>(o[r], pend[r], rnd);
-                        T t; uint32_t slot;
-                        const int prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot);   // :335 of the next level
+                        T t; uint32_t slot = 0;
+                        int prim;
+                        if (defer) {
+                            closest_hit_local<T>(sc, o[r], nd, (T)0.001, t, prim);               // :335 of the next level, LDS part
+                            parked3 = mesh_box_hit<T>(sc, o[r], nd, t);
+                        } else prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot);      // :335 of the next level
                         ++n_seg;
-                        if (prim < 0) {                               // the path leaves the scene: its last term, :365-366
+                        if (parked3) { park_t3 = t; park_prim3 = prim; pend[r].v = nd; }
+                        else if (prim < 0) {                          // the path leaves the scene: its last term, :365-366
                             const Vec<T> c = sky_term_x<T, EXT>(nd, beta[r], &ex[r]);
                             const uint32_t qi = q[r] & 0x7FFFFFFFu;
                             Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
@@ -1023,6 +1072,11 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                             pend[r].v = nd;
                             ++stg[r];
                         }
+                    }
+                    if (defer) {                                  // rays that reach the mesh's box wait for the end of the round
+                        const unsigned long long mp = __ballot(parked3);
+                        if (parked3) park(mfill + __popcll(mp & lt_mask), o[r], pend[r].v, beta[r], park_t3, q[r], park_prim3, stg[r] + 1u);
+                        mfill += (uint32_t)__popcll(mp);
                     }
                     valid[r] = hit;
                     n_hit += (uint32_t)__popcll(__ballot(hit));
@@ -1048,6 +1102,57 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                     fill += (uint32_t)__popcll(m);
                 }
                 break;
+            }
+        }
+        if (defer && mfill) {
+            // ---------------- the round's parked rays: dense batches of 64 through the tree
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the list was written by this wave's own lanes
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t base = 0; base < mfill; base += 64) {
+                const uint32_t e = base + lane;
+                bool hit = false;
+                Vec<T> o_ = mk<T>(0, 0, 0), d_ = mk<T>(0, 0, 1), beta_ = mk<T>(0, 0, 0);
+                uint32_t q_ = 0, w_ = 0;
+                if (e < mfill) {
+                    const Pack4<T> A = mlist[3 * (size_t)e], B = mlist[3 * (size_t)e + 1], C = mlist[3 * (size_t)e + 2];
+                    o_ = mk<T>(A.x, A.y, A.z); d_ = mk<T>(A.w, B.x, B.y); beta_ = mk<T>(B.z, B.w, C.x);
+                    T closest = C.y;
+                    q_ = Bits<T>::to_u32(C.z);
+                    const uint32_t pw = Bits<T>::to_u32(C.w);
+                    int prim = (int)(pw & kRefMask) - 1;
+                    const uint32_t stage_hit = pw >> kStageShift;
+                    uint32_t slot = 0;
+                    bvh_closest_hit<T>(sc, o_, d_, (T)0.001, closest, prim, slot);
+                    if (prim < 0) {                                   // the ray leaves the scene after all: sky, :365-366
+                        const uint32_t qi = q_ & 0x7FFFFFFFu;
+                        ExtState<T> ex1; ex1.flags = rc.flags; ex1.bR = 0; ex1.bG = 0; ex1.bB = 0;
+                        if (EXT && (rc.flags & kExtSpectral)) {
+                            uint32_t pi, pj, pixel, sample;
+                            path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
+                            (void)ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex1);
+                        }
+                        const Vec<T> c = sky_term_x<T, EXT>(d_, beta_, &ex1);
+                        Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
+                        if (q_ >> 31) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + c.x; l.y = l0.y + c.y; l.z = l0.z + c.z; ++n_rmw; }
+                        else ++n_store;
+                        a.L[qi] = l;
+                    } else {
+                        hit = true;
+                        o_ = o_ + d_ * closest;                       // point_at, :138 / :183
+                        w_ = ((prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim) | (stage_hit << kStageShift);
+                    }
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const uint32_t dst = region + fill + __popcll(m & lt_mask);
+                    Pack4<T> A, B; Pack2<T> C;
+                    A.x = o_.x; A.y = o_.y; A.z = o_.z; A.w = d_.x;
+                    B.x = d_.y; B.y = d_.z; B.z = beta_.x; B.w = beta_.y;
+                    C.x = beta_.z; C.y = pack_qref(q_, w_, (T)0);
+                    qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
+                    if constexpr (kRefArray) rout[dst] = w_;
+                }
+                fill += (uint32_t)__popcll(m);
             }
         }
         n_in = fill;

@@ -72,7 +72,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], mesh_list, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
     DevBuf spd32, spd64;                          // SPIRA_EXT_SPECTRAL: the SPD table, uploaded once per precision
     DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
     SceneStore scene;                         // the scene of the current call (host-array entry points)
@@ -409,7 +409,12 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     // ---- launch geometry: NW = 4*G autonomous waves per bounce kernel, each owning `cap` rays of both queues
     // workgroups per CU: the persistent kernel runs a whole pass per launch, so its launch tail is one workgroup's share of the
     // pass: 32 per CU (8 rounds of resident workgroups) measured best on S1 (16: -3.5 %, 64: -1 %, 128: -5 %; S3 likes 64-128, +1.7 %)
-    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", persistent ? 32 : 16);
+    // Mesh scenes want fewer, fatter waves: a wave's round ends with the dense traversal of the rays it parked at the mesh's box, and a
+    // traversal batch costs its slowest ray's chain of dependent node fetches whether it holds 64 rays or 10 (config 5, 81 920 triangles:
+    // f32 32 per CU 7.54 ms, 16: 6.78, 8: 7.29, 4: 7.04; f64 32: 11.67, 8: 10.29, 4: 9.68).
+    const uint32_t nt_scene = h ? h->store.nt : (triangles10 ? p->n_triangles : 0);
+    const uint32_t blocks_per_cu = !persistent ? 16 : (nt_scene > SPIRA_LDS_TRIANGLES ? (sizeof(T) == 8 ? 8 : 16) : 32);
+    const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", blocks_per_cu);
     const uint32_t wpb = spira::kBlock / 64;
     const uint32_t sub = 64 * R;                                   // rays per wave sub-chunk
     auto geometry = [&](uint64_t n_first, uint32_t &G, uint32_t &cap) {
@@ -556,6 +561,12 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 // 70: 20 963, 60: 20 052; f32 90: 30 222, 80: 30 141, 70: 29 567, 60: 28 354 — a packet costs twice the bytes in Float64, so it
                 // pays to keep a little more in registers there.  On the closed box S3 any threshold > 0 gives the full +22 % (f64).
                 pa.dense_pct = std::min<uint32_t>(env_u32("SPIRA_DENSE_PCT", sizeof(T) == 8 ? 80 : 90), 100);
+                // BVH scenes: the wave-owned lists of rays waiting for their dense traversal batch (3 packets per entry, `cap` entries per wave)
+                pa.mesh_list = nullptr;
+                if (a.scene.n_bvh_tris && p->max_depth <= 128 && env_u32("SPIRA_DEFER_MESH", 1)) {
+                    if (int rc = c.mesh_list.ensure(3 * q_rays * sizeof(P4))) return rc;
+                    pa.mesh_list = (P4 *)c.mesh_list.p;
+                }
                 geometry(n_first, G, pa.cap);
                 stat_rows = G * wpb;
                 for (int i = 0; i < 2; ++i) {
@@ -999,6 +1010,7 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qX[i].release(); }
+        c.mesh_list.release();
         c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();

@@ -101,3 +101,29 @@ def test_config5_full_size_tiling_and_bunny_sized_mesh(gpu):
     assert zlib.crc32(D.assemble(tiles, H, 8, 8).tobytes()) == zlib.crc32(a.tobytes())
     b, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.KERNEL_MEGA, seed=scenes.seed_for(5)), "f32")
     assert np.array_equal(a, b)
+
+
+def test_deferred_mesh_traversal_equals_in_place(gpu):
+    """k_path parks rays that reach the mesh's bounding box and traverses them as dense batches at the end of the round (a parked camera
+    ray is shaded one round later; packets carry their own stage).  SPIRA_DEFER_MESH=0 traverses in place: same pixels, same segments —
+    with glass (extension) and without, depth 1 .. 12."""
+    import os
+    s = scenes.scene_s4(level=4)
+    ns, nm, nt = _counts(s)
+    glass = dict(s, materials8=s["materials8"].copy())
+    glass["materials8"][2] = [0.9, 0.95, 1.0, 0, 0, 0, 0.0, -1.45]
+    old = os.environ.get("SPIRA_DEFER_MESH")
+    try:
+        for scene, flags in ((s, 0), (glass, gpu.EXT_DIELECTRIC | gpu.EXT_SPECTRAL)):
+            for depth in (1, 2, 5, 12):
+                res = {}
+                for d in ("1", "0"):
+                    os.environ["SPIRA_DEFER_MESH"] = d
+                    hdr, _ = gpu.render(*_args(scene), gpu.make_params(200, 113, 5, depth, ns, nm, nt, flags=flags | gpu.KERNEL_WAVEFRONT, seed=12, batch_rays=40000), "f32")
+                    res[d] = (hdr, gpu.counters()["segments"])
+                assert np.array_equal(res["1"][0], res["0"][0]) and res["1"][1] == res["0"][1], (flags, depth)
+    finally:
+        if old is None:
+            os.environ.pop("SPIRA_DEFER_MESH", None)
+        else:
+            os.environ["SPIRA_DEFER_MESH"] = old
