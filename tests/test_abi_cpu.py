@@ -177,6 +177,41 @@ def _c_prototypes():
     return protos
 
 
+def _check_julia_ccalls(fname, min_calls):
+    src = open(os.path.join(ROOT, "julia-spira_amd", "julia", fname)).read()
+    src = re.sub(r"#.*", "", src)
+    protos = _c_prototypes()
+    calls = re.findall(r"ccall\(\(:(spira_[a-z0-9_]+),\s*libspira\),\s*([A-Za-z0-9{}]+),\s*\(([^()]*)\)", src)
+    assert len(calls) >= min_calls, fname
+    seen = set()
+    for name, ret, args in calls:
+        assert name in protos, "%s calls %s, which include/spira_hip.h does not declare" % (fname, name)
+        cret, cargs = protos[name]
+        assert cret in _J2C[ret], (name, ret, cret)
+        jargs = [a.strip() for a in args.split(",") if a.strip()]
+        assert len(jargs) == len(cargs), (name, jargs, cargs)
+        for k, (ja, ca) in enumerate(zip(jargs, cargs)):
+            assert ca in _J2C[ja], "%s: %s argument %d: Julia %s vs C %s" % (fname, name, k + 1, ja, ca)
+        seen.add(name)
+    # the struct mirror: field order and widths of SpiraParams == spira_params
+    fields = re.search(r"struct SpiraParams(.*?)\nend", src, flags=re.S).group(1)
+    jf = re.findall(r"([a-z_0-9]+)::(UInt32|UInt64)", fields)
+    from spira_hip import _binding
+    assert [(n, {"UInt32": 4, "UInt64": 8}[t]) for n, t in jf] == [(n, C.sizeof(t)) for n, t in _binding.Params._fields_], fname
+    # flag constants used by the shim
+    hdr = open(os.path.join(ROOT, "include", "spira_hip.h")).read()
+    for const, val in re.findall(r"const (SPIRA_[A-Z_]+)\s*=\s*(0x[0-9a-fA-F]+)", src):
+        m = re.search(r"#define %s\s+(0x[0-9a-fA-F]+)u" % const, hdr)
+        assert m and int(m.group(1), 16) == int(val, 16), (fname, const)
+    return seen
+
+
+def test_julia_oracle_script_surface_ccalls_match_header():
+    """julia/Raytracer.jl = the surface of examples/julia-raytracer.jl (Float64, triangles) over the same ABI."""
+    seen = _check_julia_ccalls("Raytracer.jl", 3)
+    assert {"spira_render_f64", "spira_camera_lookat_f64", "spira_last_error"} <= seen
+
+
 def test_julia_ccalls_match_header_argument_by_argument():
     src = open(os.path.join(ROOT, "julia-spira_amd", "julia", "SPIRA.jl")).read()
     src = re.sub(r"#.*", "", src)
