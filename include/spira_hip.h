@@ -155,6 +155,7 @@ typedef struct spira_counters {
     double   kernel_ms;      /* device time of the render, HIP events on the render stream */
     double   bounce_kernel_ms;   /* device time spent in the dominant (bounce) kernel      */
     uint64_t bounce_launches;    /* launches of that kernel                                 */
+    uint64_t redone_waves;       /* waves whose pass was rendered a second time with the compiler's division (speculative division) */
 } spira_counters;
 
 /* ---- library / device ---- */

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "spira_fastdiv.h"
 
 namespace spira {
@@ -46,6 +47,132 @@ template <class T> __device__ __forceinline__ Vec<T> cross(Vec<T> a, Vec<T> b) {
 __device__ __forceinline__ float abs_t(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double abs_t(double x) { return __builtin_fabs(x); }
 template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a) { return a / sqrt_rn(dot(a, a)); }  // :27-28
+
+// ------------------------------------------------------------------ speculative IEEE division (k_path only)
+// hipcc expands a / b (correctly rounded, as Julia's) into v_div_scale x2, v_rcp, a Newton refinement of the reciprocal, a quotient with
+// one (Float64) or two (Float32) residual corrections, v_div_fmas and v_div_fixup: 11 instructions each, and a segment of a path holds
+// two vector / scalar divisions (unit normal :139, unit direction :349 / :357) and the roots of its sphere tests (:126, :133, all over
+// 2a).  While the exponents of the operands are moderate, v_div_scale returns its operand, v_div_fmas is a plain fma and v_div_fixup
+// passes its argument through, so the quotient IS the fma chain of `quotient()` below — bit for bit — and its refined reciprocal is the
+// same for every numerator over one denominator: 5 (3) instructions once, then 3 (5) per quotient, in Float64 (Float32).
+// What "moderate" costs to test decides whether this pays (measured on S1: unguarded +9 %, a guarded branch per division -1 %), so the
+// test is not made where the division stands.  A SpecDiv lane folds magnitudes it relies on into a running minimum / maximum (the
+// squares unit_vector forms anyway, b*b and the discriminant of a sphere test: non-negative values, whose high words order like the
+// values — one v_max3_u32 / v_min3_u32 each), the wave looks at them once, at the end of the pass, and a wave that saw anything
+// outside the window — a subnormal, a huge value, Inf, NaN — reports itself in PathArgs::redo; the exact instantiation of the kernel
+// (ExactDiv: the compiler's division everywhere), launched right behind, renders the pass of exactly those waves again and overwrites
+// what they wrote.  The only case that is common, a component of a vector that is exactly +0 (a 2^-20-grained random offset
+// cancelling, an axis-aligned surface), is recognised on the spot: it divides correctly.  Results are therefore those of the IEEE
+// division in every case; tests/native/div_exact.hip compares 2^32 quotients per precision over and beyond the window.
+struct ExactDiv {};
+struct SpecDiv { uint32_t lo = 0xFFFFFFFFu, hi = 0u; };
+// magnitude word of a NON-NEGATIVE value (+0 included; a NaN of either sign lands above +Inf): orders like the value
+__device__ __forceinline__ uint32_t mag_word(double x) { return (uint32_t)__double2hiint(x); }
+__device__ __forceinline__ uint32_t mag_word(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ bool is_plus_zero(double x) { return __double_as_longlong(x) == 0; }
+__device__ __forceinline__ bool is_plus_zero(float x) { return __float_as_uint(x) == 0u; }
+// The window.  Divisors — 2a of the roots, the length in unit_vector via the sum of squares — within 2^-350 .. 2^350 (Float32:
+// 2^-45 .. 2^45; v_div_scale_f32 starts scaling at an exponent difference of 96, _f64 at 768); b*b and the discriminant of a sphere
+// test below the same upper bound (so |b| and the square root, hence each numerator -b -+ sqrt, stay below its square root, doubled);
+// the single squares of a vector to normalise at least 2^-600 (2^-78) unless the component is +0: a component may be far smaller
+// than the length, its quotient only has to stay a normal number (>= 2^-300 / 2^175, resp. 2^-39 / 2^22).
+// A root's numerator has NO lower bound — it is exactly zero for every ray that starts on the sphere it is tested against whenever
+// 4a*cc drowns in b*b (:118), which is common.  Far below the window the shared-reciprocal quotient may differ from the IEEE one,
+// but both are then smaller than 2^-250 (Float32: 2^-33) in magnitude (|n| < 2^-600 resp. 2^-78, 2a >= 2^-350 resp. 2^-45), the scan
+// rejects both against t_min (:120 / :127) and never looks at their value again; closest_hit_local() checks that t_min is large
+// enough for this argument.
+template <class T> struct ExpWindow;
+template <> struct ExpWindow<double> { static constexpr uint32_t lo = (1023u - 350u) << 20, hi = (1023u + 350u) << 20, lo_sq = (1023u - 600u) << 20; };
+template <> struct ExpWindow<float> { static constexpr uint32_t lo = (127u - 45u) << 23, hi = (127u + 45u) << 23, lo_sq = (127u - 78u) << 23; };
+template <class T> __device__ __forceinline__ bool outside_window(const SpecDiv &g) { return g.lo < ExpWindow<T>::lo || g.hi >= ExpWindow<T>::hi; }
+template <class T> __device__ __forceinline__ bool outside_window(const ExactDiv &) { return false; }
+
+template <class T> struct Recip { T d, r; };
+__device__ __forceinline__ Recip<double> recip_of(double d) {
+    Recip<double> rc; rc.d = d;
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double r1 = __builtin_fma(r0, __builtin_fma(-d, r0, 1.0), r0);
+    rc.r = __builtin_fma(r1, __builtin_fma(-d, r1, 1.0), r1);
+    return rc;
+}
+__device__ __forceinline__ Recip<float> recip_of(float d) {
+    Recip<float> rc; rc.d = d;
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    rc.r = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    return rc;
+}
+__device__ __forceinline__ double quotient(double n, const Recip<double> &rc) {      // n / rc.d while both are moderate
+    const double q = n * rc.r;
+    return __builtin_fma(__builtin_fma(-rc.d, q, n), rc.r, q);
+}
+__device__ __forceinline__ float quotient(float n, const Recip<float> &rc) {
+    const float q0 = n * rc.r;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-rc.d, q0, n), rc.r, q0);
+    return __builtin_fmaf(__builtin_fmaf(-rc.d, q1, n), rc.r, q1);
+}
+// The compiler's IEEE square root, minus what moderate operands never use: hipcc scales x up when it is below 2^-767 (Float32: 2^-96)
+// and the result back down, and patches x = 0 / Inf through at the end — 8 (6) of its 18 (15) instructions.  The rest, below, is the
+// same instruction sequence, so for x inside SpecDiv's window the result has the same bits (tests/native/div_exact.hip).
+__device__ __forceinline__ double sqrt_moderate(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+}
+__device__ __forceinline__ float sqrt_moderate(float x) {
+    const float sq = __builtin_amdgcn_sqrtf(x);                               // within one ulp: pick among it and its neighbours
+    const float dn = __uint_as_float(__float_as_uint(sq) - 1u), up = __uint_as_float(__float_as_uint(sq) + 1u);
+    const float vp = __builtin_fmaf(-dn, sq, x), vs = __builtin_fmaf(-up, sq, x);
+    float r = (vp <= 0.0f) ? dn : sq;
+    r = (vs > 0.0f) ? up : r;
+    return r;
+}
+// unit_vector, :27-28
+template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a, ExactDiv &) { return normalize(a); }
+template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a, SpecDiv &g) {
+    const T sx = a.x * a.x, sy = a.y * a.y, sz = a.z * a.z;
+    const T s = sx + sy + sz;                                                // dot(a, a), same association
+    // sx >= 2^-600 puts |a.x| >= 2^-300; s < 2^350 puts every |a.i| and the length below 2^175; the length is at least each |a.i|
+    const uint32_t ms = mag_word(s);
+    g.hi = max(g.hi, ms);
+    g.lo = min(g.lo, ms);                                                    // the length as a divisor
+    const uint32_t least = min(min(mag_word(sx), mag_word(sy)), mag_word(sz));
+    if (__builtin_expect(__any(least < ExpWindow<T>::lo_sq), 0)) {           // wave-uniform, rare: a small square — fine if its component is +0
+        const bool fine = (mag_word(sx) >= ExpWindow<T>::lo_sq || is_plus_zero(a.x)) && (mag_word(sy) >= ExpWindow<T>::lo_sq || is_plus_zero(a.y)) &&
+                          (mag_word(sz) >= ExpWindow<T>::lo_sq || is_plus_zero(a.z));
+        if (!fine) g.hi = 0xFFFFFFFFu;
+    }
+    const Recip<T> rc = recip_of(sqrt_moderate(s));
+    return mk<T>(quotient(a.x, rc), quotient(a.y, rc), quotient(a.z, rc));
+}
+// all roots of one ray's sphere tests are quotients over 2a (:126, :133)
+template <class T> struct RootDiv { T two_a; Recip<T> rc; };
+template <class T> __device__ __forceinline__ RootDiv<T> root_divisor(T two_a, ExactDiv &) { RootDiv<T> r; r.two_a = two_a; r.rc.d = two_a; r.rc.r = 0; return r; }
+template <class T> __device__ __forceinline__ RootDiv<T> root_divisor(T two_a, SpecDiv &g) {
+    RootDiv<T> r; r.two_a = two_a; r.rc = recip_of(two_a);
+    const uint32_t m = mag_word(two_a);                                      // 2a = 2 d.d >= +0
+    g.lo = min(g.lo, m); g.hi = max(g.hi, m);
+    return r;
+}
+// a sphere test that has roots: b*b and its discriminant bound the numerators -b -+ sqrt(disc)
+template <class T> __device__ __forceinline__ void root_operands(T, T, ExactDiv &) {}
+template <class T> __device__ __forceinline__ void root_operands(T bb, T disc, SpecDiv &g) { g.hi = max(max(g.hi, mag_word(bb)), mag_word(disc)); }
+// sqrt(disc), :125.  The upper bound is folded by root_operands(); a discriminant below the window — exactly zero is not rare in
+// Float32, where b*b and 4a*cc are a few ulps apart for every grazing ray — takes the compiler's square root on the spot.
+template <class T> __device__ __forceinline__ T root_sqrt(T disc, ExactDiv &) { return sqrt_rn(disc); }
+template <class T> __device__ __forceinline__ T root_sqrt(T disc, SpecDiv &) {
+    T sq = sqrt_moderate(disc);
+    const bool small = mag_word(disc) < ExpWindow<T>::lo;
+    if (__builtin_expect(__any(small), 0)) { if (small) sq = sqrt_rn(disc); }       // wave-uniform branch, rare
+    return sq;
+}
+template <class T> __device__ __forceinline__ T root_over(T n, const RootDiv<T> &r, ExactDiv &) { return n / r.two_a; }
+template <class T> __device__ __forceinline__ T root_over(T n, const RootDiv<T> &r, SpecDiv &) { return quotient(n, r.rc); }
+// the smallest t_min for which a root far below the window is rejected whatever its exact value (see ExpWindow)
+template <class T> __device__ __forceinline__ void root_t_min(T, ExactDiv &) {}
+template <class T> __device__ __forceinline__ void root_t_min(T t_min, SpecDiv &g) { if (!(t_min >= (sizeof(T) == 8 ? (T)1e-70 : (T)1e-9))) g.hi = 0xFFFFFFFFu; }
 
 // ------------------------------------------------------------------ 16/32-byte packets
 template <class T> struct alignas(4 * sizeof(T)) Pack4 { T x, y, z, w; };
@@ -308,13 +435,15 @@ __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o,
 // :145-187 (LDS-resident), then the BVH for large meshes.  Returns the object index (spheres first, then
 // triangles in the caller's order) or -1.
 // The LDS-resident part of the scan (spheres, then the small triangle set); `closest` / `prim` come in as "nothing yet" and go out updated.
-template <class T>
-__device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim) {
+template <class T, class P>
+__device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, P &pol) {
     closest = (T)INFINITY;                                     // t_max = Inf, :335
     prim = -1;
     const T a = dot(d, d);                                     // :115 (same value for every sphere)
     const T two_a = (T)2.0 * a;
     const T four_a = (T)4 * a;
+    const RootDiv<T> over_2a = root_divisor<T>(two_a, pol);
+    root_t_min<T>(t_min, pol);
     // software-pipelined LDS reads: the next sphere's packet is requested before this one is tested, so the
     // ds_read latency overlaps the arithmetic instead of stalling every iteration at s_waitcnt lgkmcnt(0)
     Pack4<T> c_next = sc.sph[0];           // (slot 0 always exists in the LDS image: the block is never empty)
@@ -325,15 +454,17 @@ __device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> 
         Vec<T> oc = o - mk<T>(c.x, c.y, c.z);                  // :114
         T b = (T)2.0 * dot(oc, d);                             // :116
         T cc = dot(oc, oc) - c.w;                              // :117
-        T disc = b * b - four_a * cc;                          // :118
+        const T bb = b * b;
+        T disc = bb - four_a * cc;                             // :118
         if (!(disc < 0)) {                                     // :120
-            T sq = sqrt_rn(disc);                              // :125
-            T root = (-b - sq) / two_a;                        // :126
+            root_operands<T>(bb, disc, pol);
+            T sq = root_sqrt<T>(disc, pol);                    // :125
+            T root = root_over<T>(-b - sq, over_2a, pol);          // :126
             bool ok = !(root < t_min || root > closest);       // :130
             // :127,:131-132.  The second root is only worth a division when the first one fell short of t_min: if the first is
             // beyond `closest`, the second (-b + sq >= -b - sq, same positive divisor, correctly rounded division is monotone) is too.
             if (!ok && root < t_min) {
-                root = (-b + sq) / two_a;
+                root = root_over<T>(-b + sq, over_2a, pol);
                 ok = !(root < t_min || root > closest);
             }
             if (ok) { closest = root; prim = (int)s; }         // :137, :252
@@ -361,14 +492,24 @@ __device__ __forceinline__ bool mesh_box_hit(const SceneLds<T> &sc, Vec<T> o, Ve
     return box_entry<T>(sc.bvh_root[0], sc.bvh_root[1], o, inv, closest) >= (T)0;
 }
 
-template <class T, bool BVH>
-__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit, uint32_t &slot) {
+template <class T>
+__device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim) {
+    ExactDiv exact;
+    closest_hit_local<T>(sc, o, d, t_min, closest, prim, exact);
+}
+template <class T, bool BVH, class P>
+__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit, uint32_t &slot, P &pol) {
     T closest; int prim;
-    closest_hit_local<T>(sc, o, d, t_min, closest, prim);
+    closest_hit_local<T>(sc, o, d, t_min, closest, prim, pol);
     slot = 0;
     if (BVH) bvh_closest_hit<T>(sc, o, d, t_min, closest, prim, slot);
     t_hit = closest;
     return prim;
+}
+template <class T, bool BVH>
+__device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit, uint32_t &slot) {
+    ExactDiv exact;
+    return closest_hit<T, BVH>(sc, o, d, t_min, t_hit, slot, exact);
 }
 
 // random_in_unit_sphere, examples/julia-raytracer.jl:309-316; tries t = 1..kMaxTries.
@@ -451,13 +592,13 @@ template <class T, bool BVH> __device__ __forceinline__ int material_of(const Sc
 
 // Everything that follows a hit at `pos` (= o + d*t) except the random vector: normal, emitted term, and — when
 // the path scatters — throughput and the pending direction data.  Returns whether the emitted term is non-zero.
-template <class T, bool BVH, bool EXT = false>
+template <class T, bool BVH, bool EXT, class P>
 __device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> pos, const Vec<T> d, int prim, uint32_t slot, Vec<T> &beta,
-                                          bool scatter, Vec<T> &contrib, Pending<T> &pend, const ExtState<T> *ext = nullptr) {
+                                          bool scatter, Vec<T> &contrib, Pending<T> &pend, const ExtState<T> *ext, P &pol) {
     Vec<T> n;
     if (prim < (int)sc.n_spheres) {
         const Pack4<T> c = sc.sph[prim];
-        n = normalize(pos - mk<T>(c.x, c.y, c.z));                           // :139
+        n = normalize(pos - mk<T>(c.x, c.y, c.z), pol);                      // :139
     } else if (!BVH || prim < (int)(sc.n_spheres + sc.n_triangles)) {
         int ti = prim - (int)sc.n_spheres;
         n = mk<T>(sc.tri[3 * ti].w, sc.tri[3 * ti + 1].w, sc.tri[3 * ti + 2].w);        // :105-109, precomputed by stage_scene
@@ -492,6 +633,13 @@ __device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> po
         }
     }
     return has_contrib;
+}
+
+template <class T, bool BVH, bool EXT = false>
+__device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> pos, const Vec<T> d, int prim, uint32_t slot, Vec<T> &beta,
+                                          bool scatter, Vec<T> &contrib, Pending<T> &pend, const ExtState<T> *ext = nullptr) {
+    ExactDiv exact;
+    return shade_hit<T, BVH, EXT>(sc, pos, d, prim, slot, beta, scatter, contrib, pend, ext, exact);
 }
 
 // SPIRA_EXT_DIELECTRIC: turn a pending dielectric interaction (pend.v = geometric normal, pend.rough = refractive index) into
@@ -538,12 +686,17 @@ __device__ __forceinline__ SegInfo segment_front(const SceneLds<T> &sc, Vec<T> &
     return info;
 }
 
-template <class T>
-__device__ __forceinline__ Vec<T> segment_back(const Vec<T> pos, const Pending<T> &pend, const Vec<T> rnd) {
-    if (pend.kind == kDiffuse) return normalize((pend.v + rnd) - pos);       // :356-357
+template <class T, class P>
+__device__ __forceinline__ Vec<T> segment_back(const Vec<T> pos, const Pending<T> &pend, const Vec<T> rnd, P &pol) {
+    if (pend.kind == kDiffuse) return normalize((pend.v + rnd) - pos, pol);  // :356-357
     Vec<T> reflected = pend.v;
     if (pend.kind == kSpecRough) reflected = reflected + rnd * pend.rough;   // :347
-    return normalize(reflected);                                             // :349
+    return normalize(reflected, pol);                                        // :349
+}
+template <class T>
+__device__ __forceinline__ Vec<T> segment_back(const Vec<T> pos, const Pending<T> &pend, const Vec<T> rnd) {
+    ExactDiv exact;
+    return segment_back<T>(pos, pend, rnd, exact);
 }
 
 // Whole segment by one lane (megakernel / trace kernels).
@@ -565,15 +718,21 @@ __device__ __forceinline__ SegInfo trace_segment(const SceneLds<T> &sc, const Re
 }
 
 // Camera ray for (reference loop indices i, j; both 1-based) — examples/julia-raytracer.jl:398-400, :298-306
-template <class T>
+template <class T, class P>
 __device__ __forceinline__ void camera_ray(const RenderConst<T> &rc, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
-                                           Vec<T> &o, Vec<T> &d) {
+                                           Vec<T> &o, Vec<T> &d, P &pol) {
     T xu, xv, unused;
     rng3<T>(rng_key(rc.sA, rc.sB, pixel, sample, 0), 0, xu, xv, unused);
     T u = ((T)(i - 1) + xu) / (T)(rc.width - 1);                             // :398
     T v = ((T)(j - 1) + xv) / (T)(rc.height - 1);                            // :399
     o = rc.cam_origin;
-    d = normalize(((rc.cam_llc + rc.cam_hor * u) + rc.cam_ver * v) - o);     // :303
+    d = normalize(((rc.cam_llc + rc.cam_hor * u) + rc.cam_ver * v) - o, pol);   // :303
+}
+template <class T>
+__device__ __forceinline__ void camera_ray(const RenderConst<T> &rc, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
+                                           Vec<T> &o, Vec<T> &d) {
+    ExactDiv exact;
+    camera_ray<T>(rc, i, j, pixel, sample, o, d, exact);
 }
 
 // q (index inside the pass batch, slot-major) -> pixel / sample
@@ -595,7 +754,7 @@ __device__ __forceinline__ void path_of(const RenderConst<T> &rc, uint32_t q, ui
 template <class T> struct RayQueue { Pack4<T> *A; Pack4<T> *B; Pack2<T> *C; };
 
 struct Stats {                       // device-side counters (one per context)
-    unsigned long long segments, rays_enqueued, radiance_rmw, radiance_store;
+    unsigned long long segments, rays_enqueued, radiance_rmw, radiance_store, redone_waves;
 };
 
 template <class T> struct BounceArgs {
@@ -833,6 +992,9 @@ template <class T> struct PathArgs {
     uint32_t dense_pct;              // dense continuation threshold in % (0 = always go through the queue)
     Pack4<T> *mesh_list;             // BVH scenes: per wave `cap` entries of 3 packets — rays that reach the mesh's bounding box wait here
                                      // for the end of the round and are traversed as dense batches of 64 (NULL = traverse in place)
+    uint32_t *redo;                  // [NW] speculative division (SpecDiv above): the SPEC launch leaves 1 for a wave that has to be rendered again,
+    uint32_t redo_only;              // the exact launch behind it (redo_only = 1) renders exactly those waves.  NULL / 0: one exact launch.
+    Stats *stats;                    // redo_only: counts the waves rendered again
 };
 
 // queue word C.y: the path index (bit 31 = "L[q] already holds radiance") and, in Float64, the hit reference beside it
@@ -842,7 +1004,7 @@ __device__ __forceinline__ uint32_t unpack_q(float w) { return __float_as_uint(w
 __device__ __forceinline__ uint32_t unpack_q(double w) { return (uint32_t)(unsigned long long)__double_as_longlong(w); }
 __device__ __forceinline__ uint32_t unpack_ref(double w) { return (uint32_t)((unsigned long long)__double_as_longlong(w) >> 32); }
 
-template <class T, int R, bool BVH, bool EXT>
+template <class T, int R, bool BVH, bool EXT, bool SPEC>
 __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const PathArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
@@ -851,7 +1013,17 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t NW = gridDim.x * WPB, wid = blockIdx.x * WPB + wave;
     const RenderConst<T> &rc = a.rc;
+    typename std::conditional<SPEC, SpecDiv, ExactDiv>::type pol;   // how this instantiation divides (see SpecDiv)
+    if (!SPEC && a.redo_only) {                                  // the launch behind a speculative one: only what that one reported
+        uint32_t any = 0;
+        for (uint32_t w = 0; w < WPB; ++w) any |= a.redo[blockIdx.x * WPB + w];
+        if (!any) return;                                        // (workgroup-uniform, ahead of the barrier in stage_scene)
+    }
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // the only workgroup barrier of the kernel
+    if (!SPEC && a.redo_only) {
+        if (!a.redo[wid]) return;                                // wave-uniform; no workgroup barrier follows
+        if (lane == 0) atomicAdd(&a.stats->redone_waves, 1ull);
+    }
     Pack4<T> *s_rnd = reinterpret_cast<Pack4<T> *>(lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles)) + wave * SUB;
     const uint32_t region = wid * a.cap;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -911,14 +1083,14 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         Vec<T> d;
                         q[r] = idx;
                         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
-                        camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d);
+                        camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d, pol);
                         if (EXT) { ex[r].flags = rc.flags; if (rc.flags & kExtSpectral) beta[r] = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]); }
                         T t; uint32_t slot = 0;
                         int prim;
                         if (defer) {
-                            closest_hit_local<T>(sc, o[r], d, (T)0.001, t, prim);                   // :335, spheres and LDS triangles
+                            closest_hit_local<T>(sc, o[r], d, (T)0.001, t, prim, pol);                 // :335, spheres and LDS triangles
                             parked = mesh_box_hit<T>(sc, o[r], d, t);
-                        } else prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot);          // :335
+                        } else prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot, pol);     // :335
                         ++n_seg;
                         if (parked) { park_t = t; park_prim = prim; pend[r].v = d; }          // parked below, in uniform control flow
                         else if (prim < 0) {                      // the camera ray leaves the scene: sky, :365-366
@@ -974,7 +1146,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                             if (rc.flags & kExtSpectral) (void)ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]);
                         }
                         Vec<T> contrib;
-                        const bool has_contrib = shade_hit<T, BVH, EXT>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r], &ex[r]);
+                        const bool has_contrib = shade_hit<T, BVH, EXT>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r], &ex[r], pol);
                         // Path radiance L[q]: while bit 31 of q is clear a term is a plain store (0 + x == x exactly); the
                         // load -> add -> store round trip only remains for paths that met an emitter earlier.
                         if (has_contrib) {
@@ -1049,13 +1221,13 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                     if (pend[r].kind != kDead) {
                         Vec<T> rnd = mk<T>(0, 0, 0);
                         if (pend[r].kind != kMirror) { const Pack4<T> w = s_rnd[ent[r]]; rnd = mk<T>(w.x, w.y, w.z); }
-                        const Vec<T> nd = segment_back<T>(o[r], pend[r], rnd);
+                        const Vec<T> nd = segment_back<T>(o[r], pend[r], rnd, pol);
                         T t; uint32_t slot = 0;
                         int prim;
                         if (defer) {
-                            closest_hit_local<T>(sc, o[r], nd, (T)0.001, t, prim);               // :335 of the next level, LDS part
+                            closest_hit_local<T>(sc, o[r], nd, (T)0.001, t, prim, pol);             // :335 of the next level, LDS part
                             parked3 = mesh_box_hit<T>(sc, o[r], nd, t);
-                        } else prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot);      // :335 of the next level
+                        } else prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot, pol); // :335 of the next level
                         ++n_seg;
                         if (parked3) { park_t3 = t; park_prim3 = prim; pend[r].v = nd; }
                         else if (prim < 0) {                          // the path leaves the scene: its last term, :365-366
@@ -1164,11 +1336,13 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     for (int sft = 32; sft > 0; sft >>= 1) { n_rmw += __shfl_down(n_rmw, sft); n_seg += __shfl_down(n_seg, sft); n_store += __shfl_down(n_store, sft); }
+    const bool again = SPEC && __any(outside_window<T>(pol));    // some quotient of this wave may not be the IEEE one: the exact launch redoes the wave
     if (lane == 0) {
         a.blk_stats[4 * wid] = n_seg;
         a.blk_stats[4 * wid + 1] = n_rmw;
         a.blk_stats[4 * wid + 2] = n_store;
         a.blk_stats[4 * wid + 3] = n_enq;          // wave-uniform
+        if (SPEC) a.redo[wid] = again ? 1u : 0u;
     }
 }
 

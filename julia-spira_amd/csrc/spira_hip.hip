@@ -64,6 +64,7 @@ struct SceneStore {
     DevBuf arrays, bvh_nodes, bvh_tris;
     uint32_t ns = 0, nm = 0, nt = 0;
     uint64_t bvh_hash = 0; uint32_t bvh_n = 0; int bvh_prec = 0, bvh_depth = 0;
+    bool moderate = false;                    // every coordinate / radius of ordinary magnitude (spira::scene_scale_moderate): speculative division pays
     void release() { arrays.release(); bvh_nodes.release(); bvh_tris.release(); bvh_hash = 0; bvh_n = 0; }
 };
 
@@ -72,7 +73,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], mesh_list, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], mesh_list, redo, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
     DevBuf spd32, spd64;                          // SPIRA_EXT_SPECTRAL: the SPD table, uploaded once per precision
     DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
     SceneStore scene;                         // the scene of the current call (host-array entry points)
@@ -248,6 +249,7 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
     const size_t ns_b = (size_t)n_spheres * 5 * sizeof(T), nm_b = (size_t)n_materials * 8 * sizeof(T), nt_b = (size_t)nt_lds * 10 * sizeof(T);
     if (int rc = s.arrays.ensure(up(ns_b) + up(nm_b) + up(nt_b) + 256)) return rc;
     s.ns = n_spheres; s.nm = n_materials; s.nt = nt;
+    s.moderate = spira::scene_scale_moderate<T>(spheres5, triangles10, n_spheres, nt);
     spira::SceneGlobal<T> g;
     scene_pointers<T>(s, g);
     if (ns_b) HIP_TRY(hipMemcpyAsync((void *)g.spheres5, spheres5, ns_b, hipMemcpyHostToDevice, st));
@@ -292,15 +294,30 @@ void launch_bounce(int R, dim3 grid, size_t lds, hipStream_t st, const spira::Bo
     else launch_bounce_r<T, FIRST, false>(R, grid, lds, st, a);
 }
 
+// k_path.  `spec`: the speculative-division instantiation first (PathArgs::redo = its per-wave report), then the exact one over the
+// waves it reported (spira_device.h, SpecDiv) — two launches, the second normally a grid of workgroups that return at once.
+// spec == 2 (SPIRA_SPEC_DIV=2, tests): every wave is reported, i.e. the whole pass is rendered twice.
 template <class T>
-void launch_path(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<T> &a) {
+int launch_path(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathArgs<T> a, int spec) {
     const bool bvh = a.scene.n_bvh_tris != 0;
     const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
     const dim3 blk(spira::kBlock);
     if (ext) {           // extension instantiations (R = 2 only)
-        if (bvh) launch_lds(spira::k_path<T, 2, true, true>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, true>, grid, blk, lds, st, a);
-    } else if (R == 2) { if (bvh) launch_lds(spira::k_path<T, 2, true, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, false>, grid, blk, lds, st, a); }
-    else               { if (bvh) launch_lds(spira::k_path<T, 1, true, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 1, false, false>, grid, blk, lds, st, a); }
+        a.redo = nullptr; a.redo_only = 0;
+        if (bvh) launch_lds(spira::k_path<T, 2, true, true, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, true, false>, grid, blk, lds, st, a);
+    } else if (R == 2) {
+        if (spec) {
+            a.redo_only = 0;
+            if (bvh) launch_lds(spira::k_path<T, 2, true, false, true>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, false, true>, grid, blk, lds, st, a);
+            if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
+            a.redo_only = 1;
+        } else { a.redo = nullptr; a.redo_only = 0; }
+        if (bvh) launch_lds(spira::k_path<T, 2, true, false, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, false, false>, grid, blk, lds, st, a);
+    } else {
+        a.redo = nullptr; a.redo_only = 0;
+        if (bvh) launch_lds(spira::k_path<T, 1, true, false, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 1, false, false, false>, grid, blk, lds, st, a);
+    }
+    return 0;
 }
 
 int profile_events(Ctx &c, size_t need) {
@@ -448,6 +465,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     spira::BounceArgs<T> a{};
     if (int rc = acquire_scene<T>(c, st, h, spheres5, materials8, triangles10, p, a.scene)) return rc;
     if (int rc = attach_spd<T>(c, st, p, a.scene)) return rc;
+    const bool scene_moderate = h ? h->store.moderate : c.scene.moderate;
     fill_const<T>(a.rc, camera12, p, rows, slots);
     if (!fastdiv_selfcheck(a.rc.tile_pixels, (uint32_t)batch) || !fastdiv_selfcheck(a.rc.width, a.rc.tile_pixels) ||
         !fastdiv_selfcheck(a.rc.stripe_h ? a.rc.stripe_h : 1, rows))
@@ -574,9 +592,20 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                     pa.qref[i] = (uint32_t *)c.qR[i].p;
                 }
                 pa.blk_stats = (uint32_t *)c.blkstats.p;
+                pa.stats = (spira::Stats *)c.stats.p;
+                // speculative division (spira_device.h, SpecDiv): +7 % on S1 while (almost) no wave has to be rendered again, which is what a scene
+                // and camera of ordinary magnitudes give; a scene scaled to 1e-30 would have every wave rendered twice, so it is not tried there
+                // SPIRA_SPEC_DIV: 0 off, 1 default, 2 report every wave (the whole pass is rendered twice), 3 on even where the predictor says no
+                int spec = (int)env_u32("SPIRA_SPEC_DIV", 1);
+                if (spec == 1 && !(scene_moderate && spira::camera_scale_moderate<T>(camera12))) spec = 0;
+                if (spec == 3) spec = 1;
+                if (spec) {
+                    if (int rc = c.redo.ensure((size_t)G_max * wpb * sizeof(uint32_t))) return rc;
+                    pa.redo = (uint32_t *)c.redo.p;
+                }
                 const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4);       // + one work list per wave
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
-                launch_path<T>(R, dim3(G), lds_b, st, pa);
+                if (int rc = launch_path<T>(R, dim3(G), lds_b, st, pa, spec)) return rc;
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                 ++launches;
             } else {
@@ -988,6 +1017,7 @@ int spira_get_counters(spira_counters *out) {
         c.last.rays_enqueued = c.h_stats->rays_enqueued;
         c.last.radiance_rmw = c.h_stats->radiance_rmw;
         c.last.radiance_stores = c.h_stats->radiance_store;
+        c.last.redone_waves = c.h_stats->redone_waves;
         double bms = 0;
         for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
             float m = 0;
@@ -1011,7 +1041,7 @@ void spira_shutdown(void) {
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qX[i].release(); }
         c.mesh_list.release();
-        c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release();
+        c.redo.release(); c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
         (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop); (void)hipEventDestroy(c.ev_done);

@@ -34,4 +34,30 @@ int scene_arrays_check(const T *spheres5, const T *materials8, const T *triangle
     return 0;
 }
 
+// "Ordinary magnitudes": every coordinate is zero or within 2^-20 .. 2^20 (Float32) / 2^-64 .. 2^64 (Float64) and every radius within
+// that range.  Not a validity rule — any finite scene renders, with the same results — but the predictor of whether k_path's
+// speculative division (spira_device.h, SpecDiv) will have to render waves a second time.
+template <class T> inline bool magnitude_moderate(T v, bool zero_ok) {
+    const T lo = sizeof(T) == 8 ? (T)5.421010862427522e-20 : (T)9.5367431640625e-07, hi = (T)1 / lo;
+    const T m = std::fabs(v);
+    return (zero_ok && m == 0) || (m >= lo && m <= hi);
+}
+template <class T>
+bool scene_scale_moderate(const T *spheres5, const T *triangles10, uint32_t n_spheres, uint32_t nt) {
+    for (uint32_t i = 0; i < n_spheres; ++i) {
+        const T *s = spheres5 + 5 * (size_t)i;
+        if (!(magnitude_moderate(s[0], true) && magnitude_moderate(s[1], true) && magnitude_moderate(s[2], true) && magnitude_moderate(s[3], false))) return false;
+    }
+    for (uint32_t i = 0; i < nt; ++i)
+        for (int k = 0; k < 9; ++k)
+            if (!magnitude_moderate(triangles10[10 * (size_t)i + k], true)) return false;
+    return true;
+}
+template <class T>
+bool camera_scale_moderate(const T *camera12) {
+    for (int k = 0; k < 12; ++k)
+        if (!magnitude_moderate(camera12[k], true)) return false;
+    return true;
+}
+
 }  // namespace spira
