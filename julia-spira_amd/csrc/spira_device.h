@@ -164,9 +164,8 @@ template <class T> __device__ __forceinline__ void root_operands(T bb, T disc, S
 template <class T> __device__ __forceinline__ T root_sqrt(T disc, ExactDiv &) { return sqrt_rn(disc); }
 template <class T> __device__ __forceinline__ T root_sqrt(T disc, SpecDiv &) {
     T sq = sqrt_moderate(disc);
-    const bool small = mag_word(disc) < ExpWindow<T>::lo;
-    if (__builtin_expect(__any(small), 0)) { if (small) sq = sqrt_rn(disc); }       // wave-uniform branch, rare
-    return sq;
+    if (__builtin_expect(mag_word(disc) < ExpWindow<T>::lo, 0)) sq = sqrt_rn(disc);  // rare; (a plain divergent branch: a wave-wide vote here
+    return sq;                                                                       //  would keep the sphere loop from being unrolled)
 }
 template <class T> __device__ __forceinline__ T root_over(T n, const RootDiv<T> &r, ExactDiv &) { return n / r.two_a; }
 template <class T> __device__ __forceinline__ T root_over(T n, const RootDiv<T> &r, SpecDiv &) { return quotient(n, r.rc); }

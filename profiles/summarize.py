@@ -42,6 +42,7 @@ def main():
     if os.path.exists(st):
         lines += ["## --kernel-trace --stats", "", "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---:|---:|---:|---:|---:|---:|"]
         tot_b = cnt_b = 0
+        path_calls = []
         for r in csv.DictReader(open(st)):
             if float(r["Percentage"]) < 0.05:
                 continue
@@ -50,11 +51,28 @@ def main():
             if "k_bounce" in r["Name"] or "k_path" in r["Name"]:
                 tot_b += int(r["TotalDurationNs"])
                 cnt_b += int(r["Calls"])
+                if "k_path" in r["Name"]:
+                    path_calls.append(int(r["Calls"]))
+        if path_calls:
+            # one k_path "launch" is the speculative-division instantiation <..., true> plus the exact one <..., false> behind it, which
+            # renders again the waves the first reported (normally none: its workgroups return at once); HIP events in bench.py bracket both
+            cnt_b = max(path_calls)
         if cnt_b:
-            lines += ["", "dominant kernel (k_path / k_bounce, all instantiations): %d launches, average %.2f us" % (cnt_b, tot_b / cnt_b / 1e3), ""]
+            lines += ["", "dominant kernel (k_path: speculative launch + its exact follow-up counted as one; k_bounce: all instantiations): %d launches, average %.2f us" %
+                      (cnt_b, tot_b / cnt_b / 1e3), ""]
     kt = os.path.join(src, "trace", "trace_kernel_trace.csv")
     if os.path.exists(kt):       # launch by launch: the first launches of a process are slower than the steady state bench.py times
-        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt)) if "k_path" in r["Kernel_Name"]]
+        d = []
+        rows = sorted((r for r in csv.DictReader(open(kt)) if "k_path" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+        prev_spec = False
+        for r in rows:
+            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            spec = short(r["Kernel_Name"]).endswith(", true>")
+            if prev_spec and not spec:
+                d[-1] += us                   # the exact follow-up of the speculative launch just before it
+            else:
+                d.append(us)
+            prev_spec = spec
         if len(d) >= 4:
             half = d[len(d) // 2:]
             lines += ["k_path launch by launch (us): " + ", ".join("%.0f" % x for x in d),
@@ -117,7 +135,10 @@ def main():
     # roofline.traffic / roofline.valu fields
     for dom in ("k_path", "k_bounce"):
         ks = [k for k in agg if k.startswith(dom)]
-        nl = sum(calls[k].get("FETCH_SIZE", 0) for k in ks)
+        # launches: k_bounce instantiations are launches of their own; the k_path instantiations of one run are the speculative launch and
+        # its exact follow-up, together one launch
+        launches_of = (lambda name: max([calls[k].get(name, 0) for k in ks] or [0])) if dom == "k_path" else (lambda name: sum(calls[k].get(name, 0) for k in ks))
+        nl = launches_of("FETCH_SIZE")
         if not nl:
             continue
         import json
@@ -138,12 +159,12 @@ def main():
             wall_ns = sum(pass_dur["pmc_sq1"][k] for k in ks)        # the pass that counted SQ_INSTS_VALU and GRBM_GUI_ACTIVE
             simd_cycles = 1024 * tot("GRBM_GUI_ACTIVE") / 8
             # the class counters come from other passes of the same (deterministic) command: scale them to this pass's dispatch count
-            n_disp = max(1, sum(calls[k].get("SQ_INSTS_VALU", 0) for k in ks))
+            n_disp = max(1, launches_of("SQ_INSTS_VALU"))
             mix, covered, weighted = {}, 0.0, 0.0
             for cname, cost in VALU_COST.items():
                 if cname.startswith("other"):
                     continue
-                nd = sum(calls[k].get(cname, 0) for k in ks)
+                nd = launches_of(cname)
                 if nd:
                     cnt = tot(cname) * n_disp / nd
                     mix[cname.replace("SQ_INSTS_VALU_", "").lower()] = round(cnt / n_inst, 4)
@@ -159,7 +180,7 @@ def main():
                            "modelled_cycles_per_valu_inst": round(weighted / n_inst, 3) if mix else None, "mix": mix or None,
                            "issue_cost_table": VALU_COST if mix else None,
                            "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / max(1.0, 64 * tot("SQ_ACTIVE_INST_VALU")), 4),
-                           "valu_insts_per_launch": tot("SQ_INSTS_VALU") / max(1, sum(calls[k].get("SQ_INSTS_VALU", 0) for k in ks)),
+                           "valu_insts_per_launch": tot("SQ_INSTS_VALU") / max(1, launches_of("SQ_INSTS_VALU")),
                            "wave_cycle_shares": {"wait_any": round(tot("SQ_WAIT_ANY") / w, 3), "wait_inst_any": round(tot("SQ_WAIT_INST_ANY") / w, 3),
                                                  "active_inst_any": round(tot("SQ_ACTIVE_INST_ANY") / w, 3)} if w else None}
         json.dump(out, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
