@@ -389,13 +389,19 @@ __device__ __forceinline__ T box_entry(const Pack4<T> mn, const Pack4<T> mx, Vec
 // minimal t, ties to the LATER triangle of the caller's array (`t > closest_so_far` rejects, :179).
 // `closest` / `prim` come in holding the best hit so far (spheres, LDS triangles) and go out updated;
 // `slot` is the hit triangle's position in the reordered array.
-template <class T>
-__device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, uint32_t &slot) {
+// `lds_stack` (KL > 0): the first KL levels of the traversal stack live in the wave's LDS scratch (entry-major, [level][lane]: no bank
+// conflicts) instead of the per-lane scratch array — a pop sits on the chain of dependent node fetches, and LDS answers several times
+// faster than a scratch_load does.
+template <class T, int KL = 0>
+__device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, uint32_t &slot, uint32_t *lds_stack = nullptr) {
     const Vec<T> inv = mk<T>(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
     // most rays of a frame never come near the mesh: its bounding box sits in LDS, and a ray that misses it (same conservative slab
     // test as for the nodes) is done without a single global-memory access
     if (box_entry<T>(sc.bvh_root[0], sc.bvh_root[1], o, inv, closest) < (T)0) return;
-    uint32_t stack[kBvhStackD];
+    uint32_t stack[kBvhStackD - KL];
+    const uint32_t lane = threadIdx.x & 63;
+    auto push = [&](int level, uint32_t v) { if (KL > 0 && level < KL) lds_stack[level * 64 + lane] = v; else stack[level - KL] = v; };
+    auto pop = [&](int level) -> uint32_t { return (KL > 0 && level < KL) ? lds_stack[level * 64 + lane] : stack[level - KL]; };
     int sp = 0;
     uint32_t ref = 0;                                          // root: interior node 0
     const int base = (int)(sc.n_spheres + sc.n_triangles);
@@ -418,7 +424,7 @@ __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o,
             const bool hl = tl >= (T)0 && lref != kBvhNoneD, hr = tr >= (T)0 && rref != kBvhNoneD;
             if (hl && hr) {
                 const bool left_first = tl <= tr;
-                stack[sp++] = left_first ? rref : lref;
+                push(sp++, left_first ? rref : lref);
                 ref = left_first ? lref : rref;
                 continue;
             }
@@ -426,7 +432,7 @@ __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o,
             if (hr) { ref = rref; continue; }
         }
         if (sp == 0) break;
-        ref = stack[--sp];
+        ref = pop(--sp);
     }
 }
 
@@ -1276,7 +1282,8 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
             }
         }
         if (defer && mfill) {
-            // ---------------- the round's parked rays: dense batches of 64 through the tree
+            // ---------------- the round's parked rays: dense batches of 64 through the tree (the work list's LDS is idle now: stack levels)
+            constexpr int kLdsStack = (int)(SUB * sizeof(Pack4<T>) / (64 * sizeof(uint32_t)));      // 8 levels in Float32, 16 in Float64
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the list was written by this wave's own lanes
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             for (uint32_t base = 0; base < mfill; base += 64) {
@@ -1293,7 +1300,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                     int prim = (int)(pw & kRefMask) - 1;
                     const uint32_t stage_hit = pw >> kStageShift;
                     uint32_t slot = 0;
-                    bvh_closest_hit<T>(sc, o_, d_, (T)0.001, closest, prim, slot);
+                    bvh_closest_hit<T, kLdsStack>(sc, o_, d_, (T)0.001, closest, prim, slot, reinterpret_cast<uint32_t *>(s_rnd));
                     if (prim < 0) {                                   // the ray leaves the scene after all: sky, :365-366
                         const uint32_t qi = q_ & 0x7FFFFFFFu;
                         ExtState<T> ex1; ex1.flags = rc.flags; ex1.bR = 0; ex1.bG = 0; ex1.bB = 0;
