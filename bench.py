@@ -76,7 +76,9 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape):
            "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(kms / launches, 5), "launches": launches,
            "kernel_ms_per_step": round(kms, 4), "bytes_per_sample": round(nbytes / c["samples"], 2),
            "segments_per_sample": round(c["segments"] / c["samples"], 4), "packets_per_sample": round(c["rays_enqueued"] / c["samples"], 4),
-           "kernel_share_of_step": round(kms / max(c["kernel_ms"], 1e-9), 4), "valu": None}
+           "kernel_share_of_step": round(kms / max(c["kernel_ms"], 1e-9), 4),
+           # k_path: the speculative-division launch + the exact follow-up over the waves it reported; both inside avg_launch_ms
+           "waves_rendered_again": int(c.get("redone_waves", 0)), "valu": None}
     tag = "%s_%s" % (scene, prec) if kernel == "wavefront" else "%s_%s_%s" % (kernel, scene, prec)
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
     if is_headline_shape and os.path.exists(tfile):      # PMC figures of this same command (profiles/run_profile.sh)
