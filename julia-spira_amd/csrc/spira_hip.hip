@@ -607,7 +607,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                 if (int rc = launch_path<T>(R, dim3(G), lds_b, st, pa, spec)) return rc;
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
-                ++launches;
+                launches += (spec && R == 2 && !(p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL))) ? 2 : 1;      // the speculative launch and its exact follow-up
             } else {
                 geometry(n_first, G, a.cap);
                 stat_rows = p->max_depth * G * wpb;
