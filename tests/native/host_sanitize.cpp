@@ -196,6 +196,20 @@ static void validation_checks() {
     s5[9] = NAN; CHECK(spira::scene_arrays_check<float>(s5, m8, nullptr, 2, 2, 0, &msg) == SPIRA_E_INVALID);
     s5[9] = 2; s5[5] = INFINITY; CHECK(spira::scene_arrays_check<float>(s5, m8, nullptr, 2, 2, 0, &msg) == SPIRA_E_INVALID);
     s5[5] = 1;
+    {   // the scale predictor of k_path's speculative division: zero coordinates are ordinary, zero / tiny / huge radii and coordinates are not
+        float a5[10] = {0, 0, 0, 1, 1, 1, -2.5f, 1000.f, 0.5f, 2};
+        CHECK(spira::scene_scale_moderate<float>(a5, nullptr, 2, 0));
+        a5[3] = 0; CHECK(!spira::scene_scale_moderate<float>(a5, nullptr, 2, 0));                  // radius 0
+        a5[3] = 1; a5[6] = 1e-30f; CHECK(!spira::scene_scale_moderate<float>(a5, nullptr, 2, 0));
+        a5[6] = 3e7f; CHECK(!spira::scene_scale_moderate<float>(a5, nullptr, 2, 0));
+        a5[6] = 5e5f; CHECK(spira::scene_scale_moderate<float>(a5, nullptr, 2, 0));                 // 2^19: inside 2^-20 .. 2^20
+        double d5[5] = {1e18, 0, -1e-18, 1e-10, 1}, tt[10] = {0, 0, 0, 1, 0, 0, 0, 1e200, 0, 1}, cam[12] = {0, 1, 5, -1, 0, 0, 2, 0, 0, 0, 1.1, 0};
+        CHECK(spira::scene_scale_moderate<double>(d5, nullptr, 1, 0));                             // 2^-64 .. 2^64 in Float64
+        CHECK(!spira::scene_scale_moderate<double>(d5, tt, 1, 1));
+        CHECK(spira::camera_scale_moderate<double>(cam));
+        cam[4] = 1e-300; CHECK(!spira::camera_scale_moderate<double>(cam));
+        cam[4] = NAN; CHECK(!spira::camera_scale_moderate<double>(cam));
+    }
     double t10[10] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 1}, m8d[8] = {0};
     CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == 0);
     t10[4] = NAN; CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == SPIRA_E_INVALID);
