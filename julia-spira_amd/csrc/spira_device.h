@@ -739,6 +739,18 @@ __device__ __forceinline__ void camera_ray(const RenderConst<T> &rc, uint32_t i,
     ExactDiv exact;
     camera_ray<T>(rc, i, j, pixel, sample, o, d, exact);
 }
+// the same with the twelve camera values read from LDS (k_path: they would otherwise hold 12 / 24 SGPRs through the whole sub-chunk loop)
+template <class T, class P>
+__device__ __forceinline__ void camera_ray_lds(const RenderConst<T> &rc, const T *cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
+                                               Vec<T> &o, Vec<T> &d, P &pol) {
+    T xu, xv, unused;
+    rng3<T>(rng_key(rc.sA, rc.sB, pixel, sample, 0), 0, xu, xv, unused);
+    T u = ((T)(i - 1) + xu) / (T)(rc.width - 1);                             // :398
+    T v = ((T)(j - 1) + xv) / (T)(rc.height - 1);                            // :399
+    o = mk<T>(cam[0], cam[1], cam[2]);
+    const Vec<T> llc = mk<T>(cam[3], cam[4], cam[5]), hor = mk<T>(cam[6], cam[7], cam[8]), ver = mk<T>(cam[9], cam[10], cam[11]);
+    d = normalize(((llc + hor * u) + ver * v) - o, pol);                     // :303
+}
 
 // q (index inside the pass batch, slot-major) -> pixel / sample
 template <class T>
@@ -1024,6 +1036,12 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
         for (uint32_t w = 0; w < WPB; ++w) any |= a.redo[blockIdx.x * WPB + w];
         if (!any) return;                                        // (workgroup-uniform, ahead of the barrier in stage_scene)
     }
+    T *cam_lds = reinterpret_cast<T *>(lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles) + WPB * SUB * sizeof(Pack4<T>));
+    if (threadIdx.x < 12) {                                      // camera: origin, lower-left corner, horizontal, vertical (visible after stage_scene's barrier)
+        const Vec<T> *cv = threadIdx.x < 3 ? &rc.cam_origin : (threadIdx.x < 6 ? &rc.cam_llc : (threadIdx.x < 9 ? &rc.cam_hor : &rc.cam_ver));
+        const uint32_t cc = threadIdx.x % 3;
+        cam_lds[threadIdx.x] = cc == 0 ? cv->x : (cc == 1 ? cv->y : cv->z);
+    }
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // the only workgroup barrier of the kernel
     if (!SPEC && a.redo_only) {
         if (!a.redo[wid]) return;                                // wave-uniform; no workgroup barrier follows
@@ -1088,7 +1106,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         Vec<T> d;
                         q[r] = idx;
                         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
-                        camera_ray<T>(rc, pi, pj, pixel, sample, o[r], d, pol);
+                        camera_ray_lds<T>(rc, cam_lds, pi, pj, pixel, sample, o[r], d, pol);
                         if (EXT) { ex[r].flags = rc.flags; if (rc.flags & kExtSpectral) beta[r] = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]); }
                         T t; uint32_t slot = 0;
                         int prim;

@@ -603,7 +603,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                     if (int rc = c.redo.ensure((size_t)G_max * wpb * sizeof(uint32_t))) return rc;
                     pa.redo = (uint32_t *)c.redo.p;
                 }
-                const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4);       // + one work list per wave
+                const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4) + 128;       // + one work list per wave + the camera
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                 if (int rc = launch_path<T>(R, dim3(G), lds_b, st, pa, spec)) return rc;
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
