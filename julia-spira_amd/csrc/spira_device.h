@@ -351,13 +351,19 @@ template <class T> __device__ __forceinline__ uint32_t ref_row_j(const RenderCon
 // ------------------------------------------------------------------ closest hit (semantics A)
 // Möller–Trumbore, examples/julia-raytracer.jl:145-187, on precomputed edges.  Returns true and t when the
 // triangle is hit with t_min <= t <= t_max (the comparison with the running closest hit is the caller's).
-template <class T>
-__device__ __forceinline__ bool triangle_test(const Pack4<T> v0, const Pack4<T> e1p, const Pack4<T> e2p, Vec<T> o, Vec<T> d, T t_min, T t_max, T &t_out) {
+// f = 1 / a, :161.  SpecDiv: |a| >= 1e-8 has just been checked (:157, inside the window's lower bound in both precisions), the upper bound is folded
+template <class T> __device__ __forceinline__ T tri_recip(T aa, ExactDiv &) { return (T)1.0 / aa; }
+template <class T> __device__ __forceinline__ T tri_recip(T aa, SpecDiv &g) {
+    g.hi = max(g.hi, mag_word(abs_t(aa)));
+    return quotient((T)1.0, recip_of(aa));
+}
+template <class T, class P>
+__device__ __forceinline__ bool triangle_test(const Pack4<T> v0, const Pack4<T> e1p, const Pack4<T> e2p, Vec<T> o, Vec<T> d, T t_min, T t_max, T &t_out, P &pol) {
     Vec<T> e1 = mk<T>(e1p.x, e1p.y, e1p.z), e2 = mk<T>(e2p.x, e2p.y, e2p.z);
     Vec<T> h = cross(d, e2);                               // :153
     T aa = dot(e1, h);                                     // :154
     if (abs_t(aa) < (T)1e-8) return false;                 // :157
-    T f = (T)1.0 / aa;                                     // :161
+    T f = tri_recip<T>(aa, pol);                           // :161
     Vec<T> sv = o - mk<T>(v0.x, v0.y, v0.z);               // :162
     T u = f * dot(sv, h);                                  // :163
     if (u < (T)0.0 || u > (T)1.0) return false;            // :165
@@ -368,6 +374,11 @@ __device__ __forceinline__ bool triangle_test(const Pack4<T> v0, const Pack4<T> 
     if (t < t_min || t > t_max) return false;              // :179
     t_out = t;
     return true;
+}
+template <class T>
+__device__ __forceinline__ bool triangle_test(const Pack4<T> v0, const Pack4<T> e1p, const Pack4<T> e2p, Vec<T> o, Vec<T> d, T t_min, T t_max, T &t_out) {
+    ExactDiv exact;
+    return triangle_test<T>(v0, e1p, e2p, o, d, t_min, t_max, t_out, exact);
 }
 
 
@@ -483,7 +494,7 @@ __device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> 
             const uint32_t nx = i + 1 < sc.n_triangles ? i + 1 : i;
             v0n = sc.tri[3 * nx]; e1n = sc.tri[3 * nx + 1]; e2n = sc.tri[3 * nx + 2];
             T t;
-            if (triangle_test<T>(v0, e1, e2, o, d, t_min, closest, t)) {
+            if (triangle_test<T>(v0, e1, e2, o, d, t_min, closest, t, pol)) {
                 closest = t; prim = (int)(sc.n_spheres + i);
             }
         }

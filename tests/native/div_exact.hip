@@ -75,6 +75,14 @@ __global__ void k_check(uint32_t seed, uint32_t iters, unsigned long long *out) 
             const T z = (T)0;
             bad_s += !same(root_sqrt<T>(z, g), z);
         }
+        // ---- the triangle test's f = 1 / a (:161): divisors of both signs, |a| >= 1e-8 as the caller guarantees
+        {
+            T aa = value<T>(k, 8, Fmt<T>::span);
+            if (abs_t(aa) < (T)1e-8) aa = (T)1e-8;
+            SpecDiv g;
+            const T f = tri_recip<T>(aa, g);
+            if (!outside_window<T>(g)) { ++ok_s; bad_s += !same(f, ieee_div((T)1.0, aa)); }
+        }
         // ---- roots over 2a: numerators -b -+ sqrt(disc), bounded through b*b and disc as in closest_hit_local()
         {
             const T two_a = abs_t(value<T>(k, 4, Fmt<T>::span)), bq = value<T>(k, 5, Fmt<T>::sq_span + 4), disc = abs_t(value<T>(k, 6, Fmt<T>::span));
