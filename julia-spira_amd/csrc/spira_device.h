@@ -750,14 +750,31 @@ __device__ __forceinline__ void camera_ray(const RenderConst<T> &rc, uint32_t i,
     ExactDiv exact;
     camera_ray<T>(rc, i, j, pixel, sample, o, d, exact);
 }
+// wave-uniform value -> scalar registers
+__device__ __forceinline__ float to_scalar(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
+__device__ __forceinline__ double to_scalar(double x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)__double2loint(x)), hi = __builtin_amdgcn_readfirstlane((uint32_t)__double2hiint(x));
+    return __hiloint2double((int)hi, (int)lo);
+}
+// The divisors of the pixel coordinates (:398-399), W - 1 and H - 1, with their refined reciprocals: once per wave, in scalar registers.
+// The quotients need no window check: a numerator (i - 1) + xi is +0 or within 2^-21 .. 2^31, a divisor within 1 .. 2^31.
+template <class T> struct PixelDiv { Recip<T> w1, h1; };
+template <class T> __device__ __forceinline__ PixelDiv<T> pixel_divisors(const RenderConst<T> &rc) {
+    PixelDiv<T> p;
+    p.w1 = recip_of((T)(rc.width - 1)); p.h1 = recip_of((T)(rc.height - 1));
+    p.w1.d = to_scalar(p.w1.d); p.w1.r = to_scalar(p.w1.r); p.h1.d = to_scalar(p.h1.d); p.h1.r = to_scalar(p.h1.r);
+    return p;
+}
+template <class T> __device__ __forceinline__ T pixel_quotient(T n, const Recip<T> &rc, ExactDiv &) { return n / rc.d; }
+template <class T> __device__ __forceinline__ T pixel_quotient(T n, const Recip<T> &rc, SpecDiv &) { return quotient(n, rc); }
 // the same with the twelve camera values read from LDS (k_path: they would otherwise hold 12 / 24 SGPRs through the whole sub-chunk loop)
 template <class T, class P>
-__device__ __forceinline__ void camera_ray_lds(const RenderConst<T> &rc, const T *cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
+__device__ __forceinline__ void camera_ray_lds(const RenderConst<T> &rc, const T *cam, const PixelDiv<T> &pd, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
                                                Vec<T> &o, Vec<T> &d, P &pol) {
     T xu, xv, unused;
     rng3<T>(rng_key(rc.sA, rc.sB, pixel, sample, 0), 0, xu, xv, unused);
-    T u = ((T)(i - 1) + xu) / (T)(rc.width - 1);                             // :398
-    T v = ((T)(j - 1) + xv) / (T)(rc.height - 1);                            // :399
+    T u = pixel_quotient<T>((T)(i - 1) + xu, pd.w1, pol);                    // :398
+    T v = pixel_quotient<T>((T)(j - 1) + xv, pd.h1, pol);                    // :399
     o = mk<T>(cam[0], cam[1], cam[2]);
     const Vec<T> llc = mk<T>(cam[3], cam[4], cam[5]), hor = mk<T>(cam[6], cam[7], cam[8]), ver = mk<T>(cam[9], cam[10], cam[11]);
     d = normalize(((llc + hor * u) + ver * v) - o, pol);                     // :303
@@ -1054,6 +1071,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
         cam_lds[threadIdx.x] = cc == 0 ? cv->x : (cc == 1 ? cv->y : cv->z);
     }
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // the only workgroup barrier of the kernel
+    const PixelDiv<T> pix_div = pixel_divisors<T>(rc);
     if (!SPEC && a.redo_only) {
         if (!a.redo[wid]) return;                                // wave-uniform; no workgroup barrier follows
         if (lane == 0) atomicAdd(&a.stats->redone_waves, 1ull);
@@ -1117,7 +1135,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         Vec<T> d;
                         q[r] = idx;
                         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
-                        camera_ray_lds<T>(rc, cam_lds, pi, pj, pixel, sample, o[r], d, pol);
+                        camera_ray_lds<T>(rc, cam_lds, pix_div, pi, pj, pixel, sample, o[r], d, pol);
                         if (EXT) { ex[r].flags = rc.flags; if (rc.flags & kExtSpectral) beta[r] = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]); }
                         T t; uint32_t slot = 0;
                         int prim;

@@ -75,6 +75,15 @@ __global__ void k_check(uint32_t seed, uint32_t iters, unsigned long long *out) 
             const T z = (T)0;
             bad_s += !same(root_sqrt<T>(z, g), z);
         }
+        // ---- pixel coordinates (:398-399): (i - 1 + xi) / (W - 1), numerator +0 or 2^-21 .. 2^31, no window check in the kernel
+        {
+            const uint32_t W1 = 1u + (mixh(k ^ 0x51u) % 0x7FFFFFFEu), i1 = mixh(k ^ 0x52u) % (W1 + 1u);
+            const T xi = (k & 0x3000u) ? (T)(mixh(k ^ 0x53u) >> 11) * (T)(1.0 / 2097152.0) : (T)0;
+            const T n = (T)i1 + xi, dd = (T)W1;
+            const Recip<T> rc = recip_of(dd);
+            SpecDiv g;
+            bad_s += !same(pixel_quotient<T>(n, rc, g), ieee_div(n, dd));
+        }
         // ---- the triangle test's f = 1 / a (:161): divisors of both signs, |a| >= 1e-8 as the caller guarantees
         {
             T aa = value<T>(k, 8, Fmt<T>::span);
@@ -111,7 +120,7 @@ template <class T> int run(const char *name, int blocks, uint32_t iters, uint32_
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return 2;
     const unsigned long long n = (unsigned long long)blocks * 256 * iters;
     printf("%s unit_vector: %llu mismatching quotients in %llu unflagged vectors of %llu; roots: %llu mismatching in %llu unflagged pairs of %llu; "
-           "square roots: %llu mismatching, %llu inside the window\n", name, h[0], h[1], n, h[2], h[3], n, h[4], h[5]);
+           "square roots, 1/a, pixel quotients: %llu mismatching, %llu window-checked cases\n", name, h[0], h[1], n, h[2], h[3], n, h[4], h[5]);
     (void)hipFree(d);
     if (h[1] < n / 8 || h[3] < n / 8 || h[5] < n / 8) { printf("%s: too few unflagged cases, the test has no power\n", name); return 3; }
     return (h[0] || h[2] || h[4]) ? 1 : 0;

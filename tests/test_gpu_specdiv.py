@@ -44,7 +44,7 @@ def test_quotients_and_square_roots_are_the_ieee_ones(tmp_path):
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     for line in out.stdout.strip().splitlines():
-        assert " 0 mismatching quotients" in line and "roots: 0 mismatching" in line and "square roots: 0 mismatching" in line, line
+        assert " 0 mismatching quotients" in line and "roots: 0 mismatching" in line and "pixel quotients: 0 mismatching" in line, line
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
