@@ -61,8 +61,8 @@ template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a) { retur
 // values — one v_max3_u32 / v_min3_u32 each), the wave looks at them once, at the end of the pass, and a wave that saw anything
 // outside the window — a subnormal, a huge value, Inf, NaN — reports itself in PathArgs::redo; the exact instantiation of the kernel
 // (ExactDiv: the compiler's division everywhere), launched right behind, renders the pass of exactly those waves again and overwrites
-// what they wrote.  The only case that is common, a component of a vector that is exactly +0 (a 2^-20-grained random offset
-// cancelling, an axis-aligned surface), is recognised on the spot: it divides correctly.  Results are therefore those of the IEEE
+// what they wrote.  The only case that is common, a component of a vector that is exactly zero (a 2^-20-grained random offset
+// cancelling, an axis-aligned surface, a cross product with a coordinate axis), is handled on the spot: +-0 / length is that zero.  Results are therefore those of the IEEE
 // division in every case; tests/native/div_exact.hip compares 2^32 quotients per precision over and beyond the window.
 struct ExactDiv {};
 struct SpecDiv { uint32_t lo = 0xFFFFFFFFu, hi = 0u; };
@@ -74,7 +74,7 @@ __device__ __forceinline__ bool is_plus_zero(float x) { return __float_as_uint(x
 // The window.  Divisors — 2a of the roots, the length in unit_vector via the sum of squares — within 2^-350 .. 2^350 (Float32:
 // 2^-45 .. 2^45; v_div_scale_f32 starts scaling at an exponent difference of 96, _f64 at 768); b*b and the discriminant of a sphere
 // test below the same upper bound (so |b| and the square root, hence each numerator -b -+ sqrt, stay below its square root, doubled);
-// the single squares of a vector to normalise at least 2^-600 (2^-78) unless the component is +0: a component may be far smaller
+// the single squares of a vector to normalise at least 2^-600 (2^-78) unless the component is a zero: a component may be far smaller
 // than the length, its quotient only has to stay a normal number (>= 2^-300 / 2^175, resp. 2^-39 / 2^22).
 // A root's numerator has NO lower bound — it is exactly zero for every ray that starts on the sphere it is tested against whenever
 // 4a*cc drowns in b*b (:118), which is common.  Far below the window the shared-reciprocal quotient may differ from the IEEE one,
@@ -138,14 +138,16 @@ template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a, SpecDiv
     const uint32_t ms = mag_word(s);
     g.hi = max(g.hi, ms);
     g.lo = min(g.lo, ms);                                                    // the length as a divisor
-    const uint32_t least = min(min(mag_word(sx), mag_word(sy)), mag_word(sz));
-    if (__builtin_expect(__any(least < ExpWindow<T>::lo_sq), 0)) {           // wave-uniform, rare: a small square — fine if its component is +0
-        const bool fine = (mag_word(sx) >= ExpWindow<T>::lo_sq || is_plus_zero(a.x)) && (mag_word(sy) >= ExpWindow<T>::lo_sq || is_plus_zero(a.y)) &&
-                          (mag_word(sz) >= ExpWindow<T>::lo_sq || is_plus_zero(a.z));
-        if (!fine) g.hi = 0xFFFFFFFFu;
-    }
     const Recip<T> rc = recip_of(sqrt_moderate(s));
-    return mk<T>(quotient(a.x, rc), quotient(a.y, rc), quotient(a.z, rc));
+    Vec<T> q = mk<T>(quotient(a.x, rc), quotient(a.y, rc), quotient(a.z, rc));
+    const uint32_t least = min(min(mag_word(sx), mag_word(sy)), mag_word(sz));
+    if (__builtin_expect(__any(least < ExpWindow<T>::lo_sq), 0)) {           // wave-uniform: a small square — fine if its component is a zero
+        // +-0 / length is that zero (the fma chain turns -0 into +0: patched here); anything else this small leaves the window
+        if (mag_word(sx) < ExpWindow<T>::lo_sq) { if (a.x == (T)0) q.x = a.x; else g.hi = 0xFFFFFFFFu; }
+        if (mag_word(sy) < ExpWindow<T>::lo_sq) { if (a.y == (T)0) q.y = a.y; else g.hi = 0xFFFFFFFFu; }
+        if (mag_word(sz) < ExpWindow<T>::lo_sq) { if (a.z == (T)0) q.z = a.z; else g.hi = 0xFFFFFFFFu; }
+    }
+    return q;
 }
 // all roots of one ray's sphere tests are quotients over 2a (:126, :133)
 template <class T> struct RootDiv { T two_a; Recip<T> rc; };
@@ -1579,28 +1581,39 @@ template <class T> __device__ __forceinline__ void sincos_turn(T r, T &sn, T &cs
 // ---- the pieces of path_trace, src/spira_path_trace_kernel.metal:140-269, shared by the one-lane-per-pixel kernel
 // (k_variant_metal) and the wavefront kernel (k_path_metal)
 // Closest sphere, intersect_sphere :109-136 + the selection loop :181-189 (`t < closest_t`: ties keep the EARLIER sphere).
-template <class T>
-__device__ __forceinline__ int metal_intersect(const SceneLds<T> &sc, const Vec<T> o, const Vec<T> d, T &closest) {
+// (P: ExactDiv, or SpecDiv in k_variant_metal's speculative instantiation — the roots are quotients over a = d.d, a root below the
+// window is rejected against EPSILON like the IEEE one: see ExpWindow)
+template <class T, class P>
+__device__ __forceinline__ int metal_intersect(const SceneLds<T> &sc, const Vec<T> o, const Vec<T> d, T &closest, P &pol) {
     const T EPSILON = (T)0.0001f, INF_ = (T)1e20f;                                  // :6-7
     closest = INF_;
     int hit = -1;
     const T a = dot(d, d);
+    const RootDiv<T> over_a = root_divisor<T>(a, pol);
+    root_t_min<T>(EPSILON, pol);
     for (uint32_t s = 0; s < sc.n_spheres; ++s) {
         const Pack4<T> c = sc.sph[s];
         Vec<T> oc = o - mk<T>(c.x, c.y, c.z);
         T half_b = dot(oc, d);
         T cc = dot(oc, oc) - c.w;
-        T disc = half_b * half_b - a * cc;                                          // :117
+        const T hb2 = half_b * half_b;
+        T disc = hb2 - a * cc;                                                      // :117
         T t = INF_;
         if (disc > (T)0.0) {
-            T sq = sqrt_rn(disc);
-            T root = (-half_b - sq) / a;                                            // :120
-            if (!(root > EPSILON)) root = (-half_b + sq) / a;                       // :127
+            root_operands<T>(hb2, disc, pol);
+            T sq = root_sqrt<T>(disc, pol);
+            T root = root_over<T>(-half_b - sq, over_a, pol);                       // :120
+            if (!(root > EPSILON)) root = root_over<T>(-half_b + sq, over_a, pol);  // :127
             if (root > EPSILON) t = root;                                           // :123 / :130
         }
         if (t < closest) { closest = t; hit = (int)s; }                             // :184-188
     }
     return hit;
+}
+template <class T>
+__device__ __forceinline__ int metal_intersect(const SceneLds<T> &sc, const Vec<T> o, const Vec<T> d, T &closest) {
+    ExactDiv exact;
+    return metal_intersect<T>(sc, o, d, closest, exact);
 }
 
 // sky term of a miss, :192-198
@@ -1613,13 +1626,13 @@ template <class T> __device__ __forceinline__ Vec<T> metal_sky(const Vec<T> d, c
 // expression on the same values as the reference's per-candidate normal), flip towards the ray, emitted term, scatter (LCG draws
 // in the reference's order), throughput, Russian roulette after depth 3, throughput cut-off.  o/d: in = the segment's ray and
 // (o) its hit point, out = the scattered ray.  Returns whether the path goes on; `emitted` is thr_in * emission.
-template <class T>
+template <class T, class P>
 __device__ __forceinline__ bool metal_shade(const SceneLds<T> &sc, int hit, uint32_t depth, uint32_t &st, Vec<T> &o, Vec<T> &d, Vec<T> &thr,
-                                            Vec<T> &emitted, bool &has_emission) {
+                                            Vec<T> &emitted, bool &has_emission, P &pol) {
     const T EPSILON = (T)0.0001f;
     const Pack4<T> c = sc.sph[hit];
     const Vec<T> hit_point = o;                                                     // :203 (computed by the caller: o + d * closest)
-    Vec<T> n = normalize(hit_point - mk<T>(c.x, c.y, c.z));
+    Vec<T> n = normalize(hit_point - mk<T>(c.x, c.y, c.z), pol);
     const int mi = sc.smat[hit];
     const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
     if (dot(d, n) > (T)0.0) n = mk<T>(-n.x, -n.y, -n.z);                            // :207-209
@@ -1637,19 +1650,19 @@ __device__ __forceinline__ bool metal_shade(const SceneLds<T> &sc, int hit, uint
                 pv = mk<T>(a0 * (T)2.0 - (T)1.0, a1 * (T)2.0 - (T)1.0, a2 * (T)2.0 - (T)1.0);
                 if (dot(pv, pv) < (T)1.0) break;
             }
-            nd = normalize(nd + normalize(pv) * mb.w);                              // :222
+            nd = normalize(nd + normalize(pv, pol) * mb.w, pol);                    // :222
         }
     } else {                                                                        // cosine hemisphere, :73-93
         T r1 = lcg_uniform(st, (T)0), r2 = lcg_uniform(st, (T)0), sn, cs;
         sincos_turn<T>(r1, sn, cs);
-        T sr = sqrt_rn(r2);
+        T sr = root_sqrt<T>(r2, pol);                                               // (arguments in [0, 1]: only the lower side needs care)
         T hx = cs * sr, hy = sn * sr;
         T zz = (T)1.0 - hx * hx - hy * hy;
-        T hz = sqrt_rn(zz > (T)0.0 ? zz : (T)0.0);
+        T hz = root_sqrt<T>(zz > (T)0.0 ? zz : (T)0.0, pol);
         Vec<T> helper = abs_t(n.x) > (T)0.1 ? mk<T>(0, 1, 0) : mk<T>(1, 0, 0);      // :89
-        Vec<T> ua = normalize(cross(helper, n));
+        Vec<T> ua = normalize(cross(helper, n), pol);
         Vec<T> va = cross(n, ua);
-        nd = normalize((ua * hx + va * hy) + n * hz);                               // :93
+        nd = normalize((ua * hx + va * hy) + n * hz, pol);                          // :93
     }
     o = scatter_origin; d = nd;
     thr = mulv(thr, mk<T>(ma.x, ma.y, ma.z));                                       // :232
@@ -1663,6 +1676,12 @@ __device__ __forceinline__ bool metal_shade(const SceneLds<T> &sc, int hit, uint
     { T mx = thr.x > thr.y ? thr.x : thr.y; mx = mx > thr.z ? mx : thr.z; if (mx < (T)0.01f) return false; }   // :246
     return true;
 }
+template <class T>
+__device__ __forceinline__ bool metal_shade(const SceneLds<T> &sc, int hit, uint32_t depth, uint32_t &st, Vec<T> &o, Vec<T> &d, Vec<T> &thr,
+                                            Vec<T> &emitted, bool &has_emission) {
+    ExactDiv exact;
+    return metal_shade<T>(sc, hit, depth, st, o, d, thr, emitted, has_emission, exact);
+}
 
 // camera ray of a sample, :158-170 (x, y = gid, 0-based, y = 0 is v = 0)
 template <class T>
@@ -1673,6 +1692,16 @@ __device__ __forceinline__ void metal_camera_ray(const RenderConst<T> &rc, uint3
     T v_j = ((T)y + xi) / (T)rc.height;                                             // :162
     o = rc.cam_origin;
     d = normalize(((rc.cam_llc + rc.cam_hor * u_j) + rc.cam_ver * v_j) - o);        // :167-170
+}
+// the same through a division policy; pd: the divisors W and H with their reciprocals (numerators x + xi: +0 or 2^-24 .. 2^31)
+template <class T, class P>
+__device__ __forceinline__ void metal_camera_ray(const RenderConst<T> &rc, const PixelDiv<T> &pd, uint32_t x, uint32_t y, uint32_t &st, Vec<T> &o, Vec<T> &d, P &pol) {
+    T xi = lcg_uniform(st, (T)0);
+    T u_j = pixel_quotient<T>((T)x + xi, pd.w1, pol);                               // :161
+    xi = lcg_uniform(st, (T)0);
+    T v_j = pixel_quotient<T>((T)y + xi, pd.h1, pol);                               // :162
+    o = rc.cam_origin;
+    d = normalize(((rc.cam_llc + rc.cam_hor * u_j) + rc.cam_ver * v_j) - o, pol);   // :167-170
 }
 
 // One sample of path_trace, one lane walking the whole path.
@@ -1726,11 +1755,28 @@ __global__ __launch_bounds__(kBlock) void k_variant_cpu(const BounceArgs<T> a) {
 // pixel) at once, so every trip intersects one ray per lane instead of idling behind the wave's longest path.
 // Progressive use (`resume`): start from the sums already in accum and, when rng_states is given, from the LCG
 // states a previous call left there (the `rng_states[pixel_idx] = rng_state` of :268).
-template <class T>
-__global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a, Pack4<T> *accum, uint32_t *rng_states, int resume) {
+// SPEC: speculative division (SpecDiv; fresh renders only — a wave that has to be rendered again must find its inputs untouched, and a
+// progressive call updates sums and LCG states in place).  redo: [waves] the speculative launch's report; redo_only: the exact launch
+// behind it renders the reported waves.  A reported wave does not add its segments to the statistics: the second rendering does.
+template <class T, bool SPEC>
+__global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a, Pack4<T> *accum, uint32_t *rng_states, int resume, uint32_t *redo, int redo_only) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const uint32_t wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    typename std::conditional<SPEC, SpecDiv, ExactDiv>::type pol;
+    if (!SPEC && redo_only) {
+        uint32_t any = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) any |= redo[blockIdx.x * (kBlock / 64) + w];
+        if (!any) return;                                      // (workgroup-uniform, ahead of the barrier in stage_scene)
+    }
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
     const RenderConst<T> &rc = a.rc;
+    PixelDiv<T> pix_div;
+    pix_div.w1 = recip_of((T)rc.width); pix_div.h1 = recip_of((T)rc.height);
+    pix_div.w1.d = to_scalar(pix_div.w1.d); pix_div.w1.r = to_scalar(pix_div.w1.r); pix_div.h1.d = to_scalar(pix_div.h1.d); pix_div.h1.r = to_scalar(pix_div.h1.r);
+    if (!SPEC && redo_only) {
+        if (!redo[wave_id]) return;                            // wave-uniform; no workgroup barrier follows
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.stats->redone_waves, 1ull);
+    }
     unsigned long long nseg = 0;
     const uint32_t stride = gridDim.x * kBlock;
     uint32_t pl = blockIdx.x * kBlock + threadIdx.x;
@@ -1747,19 +1793,19 @@ __global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a,
             s = 0; new_pixel = false; new_path = true;
         }
         if (new_path) {
-            metal_camera_ray<T>(rc, pi - 1, pj - 1, st, o, d);
+            metal_camera_ray<T>(rc, pix_div, pi - 1, pj - 1, st, o, d, pol);
             thr = mk<T>(1, 1, 1); acc = mk<T>(0, 0, 0); depth = 0;
             new_path = false;
         }
         ++nseg;
         T closest;
-        const int hit = metal_intersect<T>(sc, o, d, closest);
+        const int hit = metal_intersect<T>(sc, o, d, closest, pol);
         bool ended;
         if (hit == -1) { acc = acc + metal_sky<T>(d, thr); ended = true; }            // :192-198
         else {
             o = o + d * closest;                                                      // hit_point, :203
             Vec<T> emitted; bool has_e;
-            const bool go_on = metal_shade<T>(sc, hit, depth, st, o, d, thr, emitted, has_e);
+            const bool go_on = metal_shade<T>(sc, hit, depth, st, o, d, thr, emitted, has_e, pol);
             acc = acc + emitted;                                                      // :212
             ++depth;
             ended = !go_on || depth == rc.max_depth;
@@ -1777,7 +1823,11 @@ __global__ __launch_bounds__(kBlock) void k_variant_metal(const BounceArgs<T> a,
         }
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
-    if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
+    const bool again = SPEC && (redo_only == 2 || __any(outside_window<T>(pol)));      // redo_only == 2 on the speculative launch: report every wave (tests)
+    if ((threadIdx.x & 63) == 0) {
+        if (nseg && !again) atomicAdd(&a.stats->segments, nseg);
+        if (SPEC) redo[wave_id] = again ? 1u : 0u;
+    }
 }
 
 // SEM 2 in wavefront form (k_path's organisation applied to the .metal estimator).  The estimator's LCG state runs from sample

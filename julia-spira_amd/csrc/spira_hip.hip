@@ -551,9 +551,22 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
         // one launch: every lane owns a pixel and walks its spp samples (the LCG state runs through them)
         uint32_t blocks = std::min<uint32_t>((uint32_t)((tile_pixels + spira::kBlock - 1) / spira::kBlock), max_blocks);
         a.pass = 0; a.n_first = (uint32_t)tile_pixels;
-        launch_lds(spira::k_variant_metal<T>, dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p, d_rng,
-                           progressive ? (sample0 > 0 ? 3 : 1) : 0);      // bit 0: continue the sums, bit 1: continue the LCG states
-        ++launches;
+        const int resume = progressive ? (sample0 > 0 ? 3 : 1) : 0;       // bit 0: continue the sums, bit 1: continue the LCG states
+        // speculative division as in k_path (SPIRA_SPEC_DIV): fresh renders of scenes of ordinary scale; the exact launch behind renders reported waves again
+        int spec = (int)env_u32("SPIRA_SPEC_DIV", 1);
+        if (spec == 1 && !(scene_moderate && spira::camera_scale_moderate<T>(camera12))) spec = 0;
+        if (spec == 3) spec = 1;
+        if (resume) spec = 0;
+        if (spec) {
+            if (int rc = c.redo.ensure((size_t)blocks * wpb * sizeof(uint32_t))) return rc;
+            uint32_t *redo = (uint32_t *)c.redo.p;
+            launch_lds(spira::k_variant_metal<T, true>, dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p, d_rng, resume, redo, spec == 2 ? 2 : 0);
+            launch_lds(spira::k_variant_metal<T, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p, d_rng, resume, redo, 1);
+            launches += 2;
+        } else {
+            launch_lds(spira::k_variant_metal<T, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a, (P4 *)c.accum.p, d_rng, resume, (uint32_t *)nullptr, 0);
+            ++launches;
+        }
     } else {
         for (uint32_t pass = 0; pass < n_pass; ++pass) {
             const uint32_t k_eff = std::min(slots, p->spp - pass * slots);

@@ -67,6 +67,33 @@ def test_modes_are_bit_identical(gpu, prec):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_metal_estimator_modes_are_bit_identical(gpu, prec):
+    """The .metal estimator's one-lane-per-pixel kernel speculates the same way (fresh renders only): sums, LCG states and segment
+    counts are the same with speculation off / on / every wave rendered again; a progressive continuation never speculates."""
+    s = scenes.scene_s1()
+    ns, nm, nt = _counts(s)
+    W, H, spp, depth = 320, 180, 8, 8
+    p = gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.SEM_METAL | gpu.POST_NONE, seed=41)
+    got = {}
+    for mode in (0, 1, 2):
+        with _Env(SPIRA_SPEC_DIV=mode):
+            hdr, _ = gpu.render(*_args(s), p, prec)
+            got[mode] = (hdr, gpu.counters())
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][0], got[2][0])
+    assert got[0][1]["segments"] == got[1][1]["segments"] == got[2][1]["segments"]
+    assert got[0][1]["redone_waves"] == 0 and got[1][1]["redone_waves"] == 0 and got[2][1]["redone_waves"] == (W * H + 63) // 64
+    # two progressive calls of 4 samples (the second continues sums and LCG states in place) == one call of 8
+    npdt = np.float32 if prec == "f32" else np.float64
+    sums = np.zeros((3, H, W), dtype=npdt)
+    states = np.zeros(W * H, dtype=np.uint32)
+    p4 = gpu.make_params(W, H, 4, depth, ns, nm, nt, flags=gpu.SEM_METAL, seed=41)
+    gpu.accumulate(*_args(s), p4, 0, sums, states, prec)
+    gpu.accumulate(*_args(s), p4, 4, sums, states, prec)
+    assert gpu.counters()["redone_waves"] == 0
+    assert np.array_equal(sums / npdt(8), got[0][0])
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_scene_outside_the_window_is_rendered_again_and_matches_the_oracle(gpu, oracle, prec):
     """S1 scaled by 1e-30 (1e-200 in Float64): every square underflows the window.  The predictor would switch speculation off
     (SPIRA_SPEC_DIV=1 renders it with redone_waves == 0); forced on (=3), every wave reports itself and is rendered again."""
