@@ -1479,20 +1479,28 @@ template <class T> __device__ __forceinline__ Vec<T> sa_normalize(Vec<T> a) {   
     T inv = (T)1.0 / sqrt_rn(dot(a, a));
     return mk<T>(inv * a.x, inv * a.y, inv * a.z);
 }
+template <class T> __device__ __forceinline__ Vec<T> sa_normalize(Vec<T> a, ExactDiv &) { return sa_normalize(a); }
+template <class T> __device__ __forceinline__ Vec<T> sa_normalize(Vec<T> a, SpecDiv &g) {     // 1 / length through the speculative reciprocal; the rest are products
+    const T s = a.x * a.x + a.y * a.y + a.z * a.z;                                  // dot(a, a)
+    const uint32_t ms = mag_word(s);
+    g.hi = max(g.hi, ms); g.lo = min(g.lo, ms);
+    const T inv = quotient((T)1.0, recip_of(sqrt_moderate(s)));
+    return mk<T>(inv * a.x, inv * a.y, inv * a.z);
+}
 
 // trace_ray of render_with_cpu, src/spira-metal-optimized.jl:1351-1412, iteratively:
 //   L = beta * (emission | sky) ends the path; beta *= albedo*0.5 (diffuse) | albedo (metallic).
 // Returns the number of segments; rec* (optional) record the per-segment trace.
-template <class T>
-__device__ __forceinline__ uint32_t path_cpu(const SceneLds<T> &sc, const RenderConst<T> &rc, uint32_t i, uint32_t j, uint32_t sample,
-                                             Vec<T> &L, int *rec_prims, T *rec_ts, T *rec_dirs) {
+template <class T, class P>
+__device__ __forceinline__ uint32_t path_cpu(const SceneLds<T> &sc, const RenderConst<T> &rc, const PixelDiv<T> &pd, uint32_t i, uint32_t j, uint32_t sample,
+                                             Vec<T> &L, int *rec_prims, T *rec_ts, T *rec_dirs, P &pol) {
     const uint32_t pixel = (j - 1) * rc.width + (i - 1);
     T xu, xv, unused;
     rng3<T>(rng_key(rc.sA, rc.sB, pixel, sample, 0), 0, xu, xv, unused);
-    T u = ((T)(i - 1) + xu) / (T)(rc.width - 1);                                    // :1428
-    T v = ((T)(j - 1) + xv) / (T)(rc.height - 1);                                   // :1429
+    T u = pixel_quotient<T>((T)(i - 1) + xu, pd.w1, pol);                           // :1428
+    T v = pixel_quotient<T>((T)(j - 1) + xv, pd.h1, pol);                           // :1429
     Vec<T> o = rc.cam_origin;
-    Vec<T> d = sa_normalize(((rc.cam_llc + rc.cam_hor * u) + rc.cam_ver * v) - o);  // :1431-1432 (Ray ctor normalises, :297)
+    Vec<T> d = sa_normalize(((rc.cam_llc + rc.cam_hor * u) + rc.cam_ver * v) - o, pol);  // :1431-1432 (Ray ctor normalises, :297)
     Vec<T> beta = mk<T>(1, 1, 1);
     L = mk<T>(0, 0, 0);
     uint32_t nseg = 0;
@@ -1508,14 +1516,16 @@ __device__ __forceinline__ uint32_t path_cpu(const SceneLds<T> &sc, const Render
             T a = (T)1.0;                                                           // :1364
             T half_b = dot(oc, d);
             T cc = dot(oc, oc) - c.w;
-            T disc = half_b * half_b - a * cc;                                      // :1367
+            const T hb2 = half_b * half_b;
+            T disc = hb2 - a * cc;                                                  // :1367
             if (disc > 0) {
-                T sq = sqrt_rn(disc);
+                root_operands<T>(hb2, disc, pol);
+                T sq = root_sqrt<T>(disc, pol);
                 T root = (-half_b - sq) / a;                                        // :1373
                 if (root < (T)0.001f) root = (-half_b + sq) / a;                    // :1374-1376
                 if (root > (T)0.001f && root < closest) {                           // :1378
                     closest = root; hit = true; prim = (int)s;
-                    n = sa_normalize((o + d * closest) - ctr);                      // :1381
+                    n = sa_normalize((o + d * closest) - ctr, pol);                 // :1381
                     mi = sc.smat[s];
                 }
             }
@@ -1536,17 +1546,25 @@ __device__ __forceinline__ uint32_t path_cpu(const SceneLds<T> &sc, const Render
         const Vec<T> rv = mk<T>(r0, r1, r2) - mk<T>((T)0.5, (T)0.5, (T)0.5);        // rand(Vec3) - 0.5f0
         const Vec<T> pos = o + d * closest;                                         // :1388
         if (lobe > ma.w) {                                                          // rand > metallic -> diffuse, :1397
-            Vec<T> target = (pos + n) + sa_normalize(rv);                           // :1399
-            d = sa_normalize(sa_normalize(target - pos));                           // :1400 + Ray ctor
+            Vec<T> target = (pos + n) + sa_normalize(rv, pol);                      // :1399
+            d = sa_normalize(sa_normalize(target - pos, pol), pol);                 // :1400 + Ray ctor
             beta = mulv(mk<T>(ma.x, ma.y, ma.z), beta) * (T)0.5;                    // albedo .* L .* 0.5, :1401
         } else {
             Vec<T> reflected = d - n * ((T)2.0 * dot(d, n));                        // :1404
-            d = sa_normalize(sa_normalize(reflected + rv * mb.w));                  // :1405 + ctor
+            d = sa_normalize(sa_normalize(reflected + rv * mb.w, pol), pol);        // :1405 + ctor
             beta = mulv(mk<T>(ma.x, ma.y, ma.z), beta);                             // :1406
         }
         o = pos;
     }
     return nseg;
+}
+template <class T>
+__device__ __forceinline__ uint32_t path_cpu(const SceneLds<T> &sc, const RenderConst<T> &rc, uint32_t i, uint32_t j, uint32_t sample,
+                                             Vec<T> &L, int *rec_prims, T *rec_ts, T *rec_dirs) {
+    ExactDiv exact;
+    PixelDiv<T> pd;
+    pd.w1.d = (T)(rc.width - 1); pd.w1.r = 0; pd.h1.d = (T)(rc.height - 1); pd.h1.r = 0;      // (ExactDiv divides by .d)
+    return path_cpu<T>(sc, rc, pd, i, j, sample, L, rec_prims, rec_ts, rec_dirs, exact);
 }
 
 __device__ __forceinline__ float lcg_uniform(uint32_t &st, float) { st = st * 1664525u + 1013904223u; return (float)(st & 0x00FFFFFFu) / (float)0x01000000; }
@@ -1731,22 +1749,38 @@ __device__ __forceinline__ uint32_t path_metal(const SceneLds<T> &sc, const Rend
 __device__ __forceinline__ uint32_t metal_state0(uint32_t sA, uint32_t sB, uint32_t pixel) { return mix32(mix32(sA + pixel) ^ sB); }
 
 // SEM 1 = render_with_cpu semantics: one lane per path, result into L (then k_resolve / k_finalize as usual).
-template <class T>
-__global__ __launch_bounds__(kBlock) void k_variant_cpu(const BounceArgs<T> a) {
+template <class T, bool SPEC>
+__global__ __launch_bounds__(kBlock) void k_variant_cpu(const BounceArgs<T> a, uint32_t *redo, int redo_only) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const uint32_t wave_id = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    typename std::conditional<SPEC, SpecDiv, ExactDiv>::type pol;            // as in k_variant_metal
+    if (!SPEC && redo_only) {
+        uint32_t any = 0;
+        for (uint32_t w = 0; w < kBlock / 64; ++w) any |= redo[blockIdx.x * (kBlock / 64) + w];
+        if (!any) return;
+    }
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
     const RenderConst<T> &rc = a.rc;
+    const PixelDiv<T> pix_div = pixel_divisors<T>(rc);
+    if (!SPEC && redo_only) {
+        if (!redo[wave_id]) return;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.stats->redone_waves, 1ull);
+    }
     unsigned long long nseg = 0;
     for (uint32_t idx = blockIdx.x * kBlock + threadIdx.x; idx < a.n_first; idx += gridDim.x * kBlock) {
         uint32_t pixel, sample, pi, pj;
         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
         Vec<T> Lp;
-        nseg += path_cpu<T>(sc, rc, pi, pj, sample, Lp, nullptr, nullptr, nullptr);
+        nseg += path_cpu<T>(sc, rc, pix_div, pi, pj, sample, Lp, nullptr, nullptr, nullptr, pol);
         Pack3<T> l; l.x = Lp.x; l.y = Lp.y; l.z = Lp.z;
         a.L[idx] = l;
     }
     for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
-    if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
+    const bool again = SPEC && (redo_only == 2 || __any(outside_window<T>(pol)));
+    if ((threadIdx.x & 63) == 0) {
+        if (nseg && !again) atomicAdd(&a.stats->segments, nseg);
+        if (SPEC) redo[wave_id] = again ? 1u : 0u;
+    }
 }
 
 // SEM 2 = the .metal kernel's semantics: one lane per pixel walks all spp samples (its LCG state runs through

@@ -576,8 +576,19 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
             uint32_t G = 0, stat_rows = 0;
             if (sem == SPIRA_SEM_CPU) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
-                launch_lds(spira::k_variant_cpu<T>, dim3(blocks), dim3(spira::kBlock), lds, st, a);
-                ++launches;
+                int spec = (int)env_u32("SPIRA_SPEC_DIV", 1);      // speculative division as in k_path / k_variant_metal
+                if (spec == 1 && !(scene_moderate && spira::camera_scale_moderate<T>(camera12))) spec = 0;
+                if (spec == 3) spec = 1;
+                if (spec) {
+                    if (int rc = c.redo.ensure((size_t)max_blocks * wpb * sizeof(uint32_t))) return rc;
+                    uint32_t *redo = (uint32_t *)c.redo.p;
+                    launch_lds(spira::k_variant_cpu<T, true>, dim3(blocks), dim3(spira::kBlock), lds, st, a, redo, spec == 2 ? 2 : 0);
+                    launch_lds(spira::k_variant_cpu<T, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a, redo, 1);
+                    launches += 2;
+                } else {
+                    launch_lds(spira::k_variant_cpu<T, false>, dim3(blocks), dim3(spira::kBlock), lds, st, a, (uint32_t *)nullptr, 0);
+                    ++launches;
+                }
             } else if (mega) {
                 uint32_t blocks = std::min<uint32_t>((n_first + spira::kBlock - 1) / spira::kBlock, max_blocks);
                 const bool ext = (p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;

@@ -94,6 +94,23 @@ def test_metal_estimator_modes_are_bit_identical(gpu, prec):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_cpu_estimator_modes_are_bit_identical(gpu, prec):
+    """SPIRA_SEM_CPU (render_with_cpu's estimator, one lane per path): the same three modes."""
+    s = scenes.scene_s1()
+    ns, nm, nt = _counts(s)
+    W, H, spp, depth = 320, 180, 8, 8
+    p = gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.SEM_CPU | gpu.POST_NONE, seed=43)
+    got = {}
+    for mode in (0, 1, 2):
+        with _Env(SPIRA_SPEC_DIV=mode):
+            hdr, _ = gpu.render(*_args(s), p, prec)
+            got[mode] = (hdr, gpu.counters())
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][0], got[2][0])
+    assert got[0][1]["segments"] == got[1][1]["segments"] == got[2][1]["segments"]
+    assert got[0][1]["redone_waves"] == 0 and got[1][1]["redone_waves"] == 0 and got[2][1]["redone_waves"] > 0
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_scene_outside_the_window_is_rendered_again_and_matches_the_oracle(gpu, oracle, prec):
     """S1 scaled by 1e-30 (1e-200 in Float64): every square underflows the window.  The predictor would switch speculation off
     (SPIRA_SPEC_DIV=1 renders it with redone_waves == 0); forced on (=3), every wave reports itself and is rendered again."""
