@@ -1883,16 +1883,32 @@ template <class T> struct MetalArgs {
     uint32_t *blk_stats;             // [NW][4]
     uint32_t ppw;                    // pixels per wave (a multiple of 64) == region size
     int resume;                      // bit 0: continue the sums in accum, bit 1: continue the LCG states in rng_states
+    uint32_t *redo;                  // speculative division (fresh renders only), as PathArgs::redo / redo_only (2 on the speculative launch: report every wave)
+    int redo_only;
+    Stats *stats;
 };
 
-template <class T, int R>
+template <class T, int R, bool SPEC>
 __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(const MetalArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t wid = blockIdx.x * WPB + wave;
     const RenderConst<T> &rc = a.rc;
+    typename std::conditional<SPEC, SpecDiv, ExactDiv>::type pol;
+    if (!SPEC && a.redo_only) {
+        uint32_t any = 0;
+        for (uint32_t w = 0; w < WPB; ++w) any |= a.redo[blockIdx.x * WPB + w];
+        if (!any) return;                                        // (workgroup-uniform, ahead of the barrier in stage_scene)
+    }
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    PixelDiv<T> pix_div;
+    pix_div.w1 = recip_of((T)rc.width); pix_div.h1 = recip_of((T)rc.height);
+    pix_div.w1.d = to_scalar(pix_div.w1.d); pix_div.w1.r = to_scalar(pix_div.w1.r); pix_div.h1.d = to_scalar(pix_div.h1.d); pix_div.h1.r = to_scalar(pix_div.h1.r);
+    if (!SPEC && a.redo_only) {
+        if (!a.redo[wid]) return;                                // wave-uniform; no workgroup barrier follows
+        if (lane == 0) atomicAdd(&a.stats->redone_waves, 1ull);
+    }
     const uint32_t region = wid * a.ppw;                          // first pixel of this wave == first slot of its queue regions
     const uint32_t n_pix = region < rc.tile_pixels ? (rc.tile_pixels - region < a.ppw ? rc.tile_pixels - region : a.ppw) : 0u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -1946,9 +1962,9 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(
                             uint32_t pixel, sample, pi, pj;
                             path_of<T>(rc, q, 0, pi, pj, pixel, sample);
                             st = a.rng_states[q];
-                            metal_camera_ray<T>(rc, pi - 1, pj - 1, st, o, d);
+                            metal_camera_ray<T>(rc, pix_div, pi - 1, pj - 1, st, o, d, pol);
                             T closest;
-                            hit = metal_intersect<T>(sc, o, d, closest);
+                            hit = metal_intersect<T>(sc, o, d, closest, pol);
                             ++n_seg;
                             if (hit < 0) { finish(q, false, true, metal_sky<T>(d, thr), st); alive = false; }
                             else o = o + d * closest;                                   // hit_point, :203
@@ -1963,7 +1979,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(
                             const uint32_t pl = q & 0x7FFFFFFFu;
                             bool has_l = (q >> 31) != 0;
                             Vec<T> emitted; bool has_e;
-                            const bool go_on = metal_shade<T>(sc, hit, stage, st, o, d, thr, emitted, has_e);
+                            const bool go_on = metal_shade<T>(sc, hit, stage, st, o, d, thr, emitted, has_e, pol);
                             if (go_on && stage + 1 < rc.max_depth) {
                                 if (has_e) {                                          // the path continues: park the emitted term in L
                                     Pack3<T> l; l.x = emitted.x; l.y = emitted.y; l.z = emitted.z;
@@ -1972,7 +1988,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(
                                     has_l = true; q |= 0x80000000u;
                                 }
                                 T closest;
-                                const int nh = metal_intersect<T>(sc, o, d, closest);
+                                const int nh = metal_intersect<T>(sc, o, d, closest, pol);
                                 ++n_seg;
                                 if (nh < 0) finish(pl, has_l, true, metal_sky<T>(d, thr), st);
                                 else { hit_next = true; o = o + d * closest; ref = (uint32_t)nh; }
@@ -2001,11 +2017,13 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(
         }
     }
     for (int sft = 32; sft > 0; sft >>= 1) { n_seg += __shfl_down(n_seg, sft); n_rmw += __shfl_down(n_rmw, sft); n_store += __shfl_down(n_store, sft); }
+    const bool again = SPEC && (a.redo_only == 2 || __any(outside_window<T>(pol)));
     if (lane == 0) {
         a.blk_stats[4 * wid] = n_seg;
         a.blk_stats[4 * wid + 1] = n_rmw;
         a.blk_stats[4 * wid + 2] = n_store;
         a.blk_stats[4 * wid + 3] = n_enq;
+        if (SPEC) a.redo[wid] = again ? 1u : 0u;
     }
 }
 

@@ -541,8 +541,21 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
         ma.resume = progressive ? (sample0 > 0 ? 3 : 1) : 0;          // bit 0: continue the sums, bit 1: continue the LCG states
         if (int rc = profile_events(c, 2)) return rc;
         HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
-        if (R == 2) launch_lds(spira::k_path_metal<T, 2>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
-        else launch_lds(spira::k_path_metal<T, 1>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
+        int spec = (int)env_u32("SPIRA_SPEC_DIV", 1);      // speculative division as in k_path (fresh renders only: a progressive call updates sums and states in place)
+        if (spec == 1 && !(scene_moderate && spira::camera_scale_moderate<T>(camera12))) spec = 0;
+        if (spec == 3) spec = 1;
+        if (ma.resume || R != 2) spec = 0;
+        ma.stats = (spira::Stats *)c.stats.p; ma.redo = nullptr; ma.redo_only = 0;
+        if (spec) {
+            if (int rc = c.redo.ensure((size_t)Gm * wpb * sizeof(uint32_t))) return rc;
+            ma.redo = (uint32_t *)c.redo.p;
+            ma.redo_only = spec == 2 ? 2 : 0;
+            launch_lds(spira::k_path_metal<T, 2, true>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
+            ma.redo_only = 1;
+            ++launches;
+        }
+        if (R == 2) launch_lds(spira::k_path_metal<T, 2, false>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
+        else launch_lds(spira::k_path_metal<T, 1, false>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
         HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
         hipLaunchKernelGGL(spira::k_fold_stats, dim3(1), dim3(64), 0, st, (const uint32_t *)c.blkstats.p, Gm * wpb, (spira::Stats *)c.stats.p);
         launches += 2;

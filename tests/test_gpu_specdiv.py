@@ -82,6 +82,14 @@ def test_metal_estimator_modes_are_bit_identical(gpu, prec):
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][0], got[2][0])
     assert got[0][1]["segments"] == got[1][1]["segments"] == got[2][1]["segments"]
     assert got[0][1]["redone_waves"] == 0 and got[1][1]["redone_waves"] == 0 and got[2][1]["redone_waves"] == (W * H + 63) // 64
+    # the wavefront form of the estimator (k_path_metal): same sums in all three modes, and the same as the one-lane kernel's
+    pw = gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=gpu.SEM_METAL | gpu.KERNEL_WAVEFRONT | gpu.POST_NONE, seed=41)
+    for mode in (0, 1, 2):
+        with _Env(SPIRA_SPEC_DIV=mode):
+            hdr, _ = gpu.render(*_args(s), pw, prec)
+            c = gpu.counters()
+        assert np.array_equal(hdr, got[0][0]) and c["segments"] == got[0][1]["segments"], mode
+        assert (c["redone_waves"] > 0) == (mode == 2), (mode, c["redone_waves"])
     # two progressive calls of 4 samples (the second continues sums and LCG states in place) == one call of 8
     npdt = np.float32 if prec == "f32" else np.float64
     sums = np.zeros((3, H, W), dtype=npdt)
