@@ -303,7 +303,12 @@ int launch_path(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathArgs<T>
     const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
     const dim3 blk(spira::kBlock);
     if (ext) {           // extension instantiations (R = 2 only)
-        a.redo = nullptr; a.redo_only = 0;
+        if (spec) {
+            a.redo_only = 0;
+            if (bvh) launch_lds(spira::k_path<T, 2, true, true, true>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, true, true>, grid, blk, lds, st, a);
+            if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
+            a.redo_only = 1;
+        } else { a.redo = nullptr; a.redo_only = 0; }
         if (bvh) launch_lds(spira::k_path<T, 2, true, true, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, true, false>, grid, blk, lds, st, a);
     } else if (R == 2) {
         if (spec) {
@@ -644,7 +649,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                 if (int rc = launch_path<T>(R, dim3(G), lds_b, st, pa, spec)) return rc;
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
-                launches += (spec && R == 2 && !(p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL))) ? 2 : 1;      // the speculative launch and its exact follow-up
+                launches += (spec && R == 2) ? 2 : 1;      // the speculative launch and its exact follow-up
             } else {
                 geometry(n_first, G, a.cap);
                 stat_rows = p->max_depth * G * wpb;

@@ -102,6 +102,25 @@ def test_metal_estimator_modes_are_bit_identical(gpu, prec):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_extension_instantiations_modes_are_bit_identical(gpu, prec):
+    """The dielectric / spectral instantiations of k_path speculate too (their own divisions — 1/ior, Schlick's r0, Snell's square root —
+    stay the compiler's)."""
+    from test_gpu_ext import glass_scene
+    s = glass_scene()
+    ns, nm, nt = _counts(s)
+    for ext in (gpu.EXT_DIELECTRIC, gpu.EXT_DIELECTRIC | gpu.EXT_SPECTRAL):
+        p = gpu.make_params(240, 136, 6, 8, ns, nm, nt, flags=ext | gpu.POST_NONE, seed=17)
+        got = {}
+        for mode in (0, 1, 2):
+            with _Env(SPIRA_SPEC_DIV=mode):
+                hdr, _ = gpu.render(*_args(s), p, prec)
+                got[mode] = (hdr, gpu.counters())
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][0], got[2][0])
+        assert got[0][1]["segments"] == got[1][1]["segments"] == got[2][1]["segments"]
+        assert got[1][1]["redone_waves"] == 0 and got[2][1]["redone_waves"] > 0
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_cpu_estimator_modes_are_bit_identical(gpu, prec):
     """SPIRA_SEM_CPU (render_with_cpu's estimator, one lane per path): the same three modes."""
     s = scenes.scene_s1()
