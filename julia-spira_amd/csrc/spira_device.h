@@ -48,7 +48,7 @@ __device__ __forceinline__ float abs_t(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double abs_t(double x) { return __builtin_fabs(x); }
 template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a) { return a / sqrt_rn(dot(a, a)); }  // :27-28
 
-// ------------------------------------------------------------------ speculative IEEE division (k_path only)
+// ------------------------------------------------------------------ speculative IEEE division (k_path, k_path_metal, k_variant_metal, k_variant_cpu)
 // hipcc expands a / b (correctly rounded, as Julia's) into v_div_scale x2, v_rcp, a Newton refinement of the reciprocal, a quotient with
 // one (Float64) or two (Float32) residual corrections, v_div_fmas and v_div_fixup: 11 instructions each, and a segment of a path holds
 // two vector / scalar divisions (unit normal :139, unit direction :349 / :357) and the roots of its sphere tests (:126, :133, all over
@@ -62,15 +62,13 @@ template <class T> __device__ __forceinline__ Vec<T> normalize(Vec<T> a) { retur
 // outside the window — a subnormal, a huge value, Inf, NaN — reports itself in PathArgs::redo; the exact instantiation of the kernel
 // (ExactDiv: the compiler's division everywhere), launched right behind, renders the pass of exactly those waves again and overwrites
 // what they wrote.  The only case that is common, a component of a vector that is exactly zero (a 2^-20-grained random offset
-// cancelling, an axis-aligned surface, a cross product with a coordinate axis), is handled on the spot: +-0 / length is that zero.  Results are therefore those of the IEEE
-// division in every case; tests/native/div_exact.hip compares 2^32 quotients per precision over and beyond the window.
+// cancelling, an axis-aligned surface, a cross product with a coordinate axis), is handled on the spot: +-0 / length is that zero.
+// Results are therefore those of the IEEE division in every case; tests/native/div_exact.hip compares 2^32 quotients per precision over and beyond the window.
 struct ExactDiv {};
 struct SpecDiv { uint32_t lo = 0xFFFFFFFFu, hi = 0u; };
 // magnitude word of a NON-NEGATIVE value (+0 included; a NaN of either sign lands above +Inf): orders like the value
 __device__ __forceinline__ uint32_t mag_word(double x) { return (uint32_t)__double2hiint(x); }
 __device__ __forceinline__ uint32_t mag_word(float x) { return __float_as_uint(x); }
-__device__ __forceinline__ bool is_plus_zero(double x) { return __double_as_longlong(x) == 0; }
-__device__ __forceinline__ bool is_plus_zero(float x) { return __float_as_uint(x) == 0u; }
 // The window.  Divisors — 2a of the roots, the length in unit_vector via the sum of squares — within 2^-350 .. 2^350 (Float32:
 // 2^-45 .. 2^45; v_div_scale_f32 starts scaling at an exponent difference of 96, _f64 at 768); b*b and the discriminant of a sphere
 // test below the same upper bound (so |b| and the square root, hence each numerator -b -+ sqrt, stay below its square root, doubled);
