@@ -433,9 +433,10 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     // pass: 32 per CU (8 rounds of resident workgroups) measured best on S1 (16: -3.5 %, 64: -1 %, 128: -5 %; S3 likes 64-128, +1.7 %)
     // Mesh scenes want fewer, fatter waves: a wave's round ends with the dense traversal of the rays it parked at the mesh's box, and a
     // traversal batch costs its slowest ray's chain of dependent node fetches whether it holds 64 rays or 10 (config 5, 81 920 triangles:
-    // f32 32 per CU 7.54 ms, 16: 6.78, 8: 7.29, 4: 7.04; f64 32: 11.67, 8: 10.29, 4: 9.68).
+    // f32 32 per CU 7.54 ms, 16: 6.78, 8: 7.29, 4: 7.04; f64 32: 11.67, 8: 10.29, 4: 9.68; re-measured with the round's final kernels: f32 16: 6.83, 8: 7.02, 32: 7.39,
+    // f64 4: 9.54, 8: 10.13, 16: 10.49 — and counts that are not powers of two lose 10-40 %: the grid no longer divides evenly over 8 XCDs x 32 CUs).
     const uint32_t nt_scene = h ? h->store.nt : (triangles10 ? p->n_triangles : 0);
-    const uint32_t blocks_per_cu = !persistent ? 16 : (nt_scene > SPIRA_LDS_TRIANGLES ? (sizeof(T) == 8 ? 8 : 16) : 32);
+    const uint32_t blocks_per_cu = !persistent ? 16 : (nt_scene > SPIRA_LDS_TRIANGLES ? (sizeof(T) == 8 ? 4 : 16) : 32);
     const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", blocks_per_cu);
     const uint32_t wpb = spira::kBlock / 64;
     const uint32_t sub = 64 * R;                                   // rays per wave sub-chunk
