@@ -226,12 +226,12 @@ template <class T> struct SceneLds {
     const int *smat;
     const int *tmat;
     uint32_t n_spheres, n_triangles;
-    // large meshes: BVH in global memory (spira_bvh.h), L2 / Infinity-Cache resident
-    const Pack4<T> *bvh_nodes;
+    // large meshes: 8-wide quantised BVH in global memory (spira_bvh.h), L2 / Infinity-Cache resident
+    const uint4 *bvh_nodes;     // 5 x uint4 per node slot
     const Pack4<T> *bvh_tris;
     uint32_t n_bvh_tris;
-    const Pack4<T> *bvh_root;   // LDS: {min, max} of the whole mesh (union of the root's two padded child boxes): a ray that misses it
-                                // never touches the tree in global memory
+    const Pack4<T> *bvh_root;   // LDS: {min}, {max} of the whole mesh's padded box (caller's coordinates, render precision) — a ray that misses
+                                // it never touches the tree — and {centre, scale} of the normalised frame the node boxes live in
     const T *spd;           // SPIRA_EXT_SPECTRAL: kSpdRows x kSpdN table (include/spira_spd.h) staged behind the scene, else unused
 };
 
@@ -243,9 +243,11 @@ template <class T> struct SceneGlobal {     // flat arrays exactly as passed thr
     const T *materials8;    // :531-541
     const T *triangles10;   // staged into LDS (small counts); NULL / 0 when the mesh goes through the BVH
     uint32_t n_spheres, n_materials, n_triangles;
-    const Pack4<T> *bvh_nodes;
-    const Pack4<T> *bvh_tris;
+    const uint4 *bvh_nodes;         // spira_bvh.h: 5 x uint4 per node slot, slot 0 = root
+    const Pack4<T> *bvh_tris;       // 3 packets per triangle, node order
+    const Pack4<T> *bvh_frame;      // 3 packets: root box min, max (caller's coordinates), {centre, scale}
     uint32_t n_bvh_tris;
+    uint32_t bvh_slots;             // node slots in bvh_nodes
     const T *spd;           // device copy of the SPD table, or NULL (extension off)
 };
 
@@ -262,7 +264,7 @@ template <class T> __host__ __device__ inline size_t scene_lds_bytes(uint32_t ns
     b = (b + 31) & ~(size_t)31;
     b += (size_t)kSpdRows * kSpdN * sizeof(T);        // the SPD table's slot (1.7 KB in Float64; filled only in spectral mode)
     b = (b + 31) & ~(size_t)31;
-    b += 2 * sizeof(Pack4<T>);                        // the mesh's bounding box (BVH scenes)
+    b += 3 * sizeof(Pack4<T>);                        // the mesh's bounding box and normalised frame (BVH scenes)
     return (b + 31) & ~(size_t)31;
 }
 
@@ -305,13 +307,7 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
     if (g.spd)
         for (uint32_t i = threadIdx.x; i < (uint32_t)(kSpdRows * kSpdN); i += blockDim.x) spd[i] = g.spd[i];
     Pack4<T> *root = reinterpret_cast<Pack4<T> *>(lds + ((spd_off + (size_t)kSpdRows * kSpdN * sizeof(T) + 31) & ~(size_t)31));
-    if (g.n_bvh_tris && threadIdx.x == 0) {            // union of the root node's two child boxes (an absent child's box is inverted: +inf / -inf)
-        const Pack4<T> l0 = g.bvh_nodes[0], l1 = g.bvh_nodes[1], r0 = g.bvh_nodes[2], r1 = g.bvh_nodes[3];
-        Pack4<T> mn, mx;
-        mn.x = min_nn(l0.x, r0.x); mn.y = min_nn(l0.y, r0.y); mn.z = min_nn(l0.z, r0.z); mn.w = 0;
-        mx.x = max_nn(l1.x, r1.x); mx.y = max_nn(l1.y, r1.y); mx.z = max_nn(l1.z, r1.z); mx.w = 0;
-        root[0] = mn; root[1] = mx;
-    }
+    if (g.n_bvh_tris && threadIdx.x < 3) root[threadIdx.x] = g.bvh_frame[threadIdx.x];
     __syncthreads();
     SceneLds<T> sc;
     sc.sph = sph; sc.tri = tri; sc.mat = mat; sc.smat = smat; sc.tmat = tmat;
@@ -382,7 +378,6 @@ __device__ __forceinline__ bool triangle_test(const Pack4<T> v0, const Pack4<T> 
 }
 
 
-constexpr uint32_t kBvhLeafFlagD = 0x80000000u, kBvhNoneD = 0xFFFFFFFFu;
 constexpr int kBvhStackD = 64;
 
 // Conservative ray / padded-box slab test: entry distance, or -1 when the box cannot contain a hit <= best.
@@ -396,55 +391,179 @@ __device__ __forceinline__ T box_entry(const Pack4<T> mn, const Pack4<T> mx, Vec
     return (enter <= exit_ && exit_ >= (T)0 && enter <= best) ? max_nn(enter, (T)0) : (T)-1;
 }
 
-// BVH traversal that returns exactly what the reference's linear scan over the same triangles returns:
-// minimal t, ties to the LATER triangle of the caller's array (`t > closest_so_far` rejects, :179).
-// `closest` / `prim` come in holding the best hit so far (spheres, LDS triangles) and go out updated;
-// `slot` is the hit triangle's position in the reordered array.
-// `lds_stack` (KL > 0): the first KL levels of the traversal stack live in the wave's LDS scratch (entry-major, [level][lane]: no bank
-// conflicts) instead of the per-lane scratch array — a pop sits on the chain of dependent node fetches, and LDS answers several times
-// faster than a scratch_load does.
+// ------------------------------------------------------------------ 8-wide quantised BVH (layout and rationale: spira_bvh.h)
+// Returns exactly what the reference's linear scan over the same triangles returns: minimal t, ties to the LATER triangle of the
+// caller's array (`t > closest_so_far` rejects, :179).  Box tests run in Float32 in the mesh's normalised frame whatever the render
+// precision (they only prune, conservatively); the triangle test is the scan's own arithmetic in T on the caller's coordinates.
+// A ray is assumed to have a direction of unit length (every ray of the kernels is normalised): its parameter then measures
+// distance, which is what the clamp of 1/d below and the padding of the boxes are sized for.
+struct Bvh8Ray {
+    float ox, oy, oz;        // origin in the normalised frame: the point where the ray enters the mesh's box (or its own origin inside it)
+    float ix, iy, iz;        // 1 / d, magnitude clamped to 2^40 (a slab the ray runs parallel to: inside -> (-huge, huge), outside -> beyond every exit)
+    uint32_t oct;            // bit k: d_k < 0
+    float best;              // closest hit so far as a distance from (ox, oy, oz), normalised units, rounded up
+};
+template <class T> struct Bvh8Walk {      // one lane's traversal state
+    uint32_t G;              // current node group: child_base << 8 | hit children still to visit, bit (slot ^ oct): ascending = front to back
+    uint32_t trimask;        // triangles of the current node still to test (bit j: tri_base + j)
+    uint32_t tri_base;
+    int sp;
+    T t0;                    // ray parameter of (ox, oy, oz)
+};
+
+__device__ __forceinline__ float bvh8_rcp(float dx, bool neg) {
+    const float a = __builtin_fmaxf(__builtin_fabsf(dx), 9.094947017729282e-13f);     // 2^-40
+    const float r = __builtin_amdgcn_rcpf(a);
+    return neg ? -r : r;
+}
+__device__ __forceinline__ float bvh8_best(float x) { return x * 1.00000095367431640625f; }      // (1 + 2^-20): rounded up for sure
+
+// Root box test (render precision, caller's coordinates) and the ray's Float32 side.  false: the ray cannot hit the mesh before `closest`.
+template <class T>
+__device__ __forceinline__ bool bvh8_enter(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T closest, Bvh8Ray &r, T &t0) {
+    const Vec<T> inv = mk<T>(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
+    const T te = box_entry<T>(sc.bvh_root[0], sc.bvh_root[1], o, inv, closest);
+    if (te < (T)0) return false;
+    t0 = te;
+    const Pack4<T> fr = sc.bvh_root[2];
+    const Vec<T> on = ((o + d * te) - mk<T>(fr.x, fr.y, fr.z)) * fr.w;
+    r.ox = (float)on.x; r.oy = (float)on.y; r.oz = (float)on.z;
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const bool nx = dx < 0.0f, ny = dy < 0.0f, nz = dz < 0.0f;
+    r.oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+    r.ix = bvh8_rcp(dx, nx); r.iy = bvh8_rcp(dy, ny); r.iz = bvh8_rcp(dz, nz);
+    r.best = bvh8_best((float)((closest - te) * fr.w));
+    return true;
+}
+
+__device__ __forceinline__ float bvh8_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }      // v_cvt_f32_ubyteK
+
+// One node: slab tests of its 8 children.  Out: ih = hit child NODES, bit (slot ^ oct); trimask / tri_base = triangles of the hit leaf children.
+__device__ __forceinline__ void bvh8_node(const uint4 w0, const uint4 w1, const uint4 w2, const uint4 w3, const uint4 w4, const Bvh8Ray &r,
+                                          uint32_t &ih, uint32_t &child_base, uint32_t &trimask, uint32_t &tri_base) {
+    const float sx = __uint_as_float((w0.w & 0xFFu) << 23), sy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23);
+    const uint32_t imask = w0.w >> 24;
+    const float ax = sx * r.ix, ay = sy * r.iy, az = sz * r.iz;
+    const float bx = (__uint_as_float(w0.x) - r.ox) * r.ix, by = (__uint_as_float(w0.y) - r.oy) * r.iy, bz = (__uint_as_float(w0.z) - r.oz) * r.iz;
+    // near / far planes per axis by the sign of the direction: lo_x = w2.xy, lo_y = w2.zw, lo_z = w3.xy, hi_x = w3.zw, hi_y = w4.xy, hi_z = w4.zw
+    const bool nx = (r.oct & 1u) != 0, ny = (r.oct & 2u) != 0, nz = (r.oct & 4u) != 0;
+    const uint32_t nxw[2] = {nx ? w3.z : w2.x, nx ? w3.w : w2.y}, fxw[2] = {nx ? w2.x : w3.z, nx ? w2.y : w3.w};
+    const uint32_t nyw[2] = {ny ? w4.x : w2.z, ny ? w4.y : w2.w}, fyw[2] = {ny ? w2.z : w4.x, ny ? w2.w : w4.y};
+    const uint32_t nzw[2] = {nz ? w4.z : w3.x, nz ? w4.w : w3.y}, fzw[2] = {nz ? w3.x : w4.z, nz ? w3.y : w4.w};
+    uint32_t hits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int wi = i >> 2, k = i & 3;
+        const float tnx = __builtin_fmaf(bvh8_byte(nxw[wi], k), ax, bx), tfx = __builtin_fmaf(bvh8_byte(fxw[wi], k), ax, bx);
+        const float tny = __builtin_fmaf(bvh8_byte(nyw[wi], k), ay, by), tfy = __builtin_fmaf(bvh8_byte(fyw[wi], k), ay, by);
+        const float tnz = __builtin_fmaf(bvh8_byte(nzw[wi], k), az, bz), tfz = __builtin_fmaf(bvh8_byte(fzw[wi], k), az, bz);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, r.best));
+        hits |= (tn <= tf) ? (1u << i) : 0u;
+    }
+    uint32_t ihs = hits & imask, lh = hits & ~imask;
+    if (nx) ihs = ((ihs & 0x55u) << 1) | ((ihs >> 1) & 0x55u);       // bit s -> bit s ^ oct
+    if (ny) ihs = ((ihs & 0x33u) << 2) | ((ihs >> 2) & 0x33u);
+    if (nz) ihs = ((ihs & 0x0Fu) << 4) | (ihs >> 4);
+    ih = ihs;
+    child_base = w1.x; tri_base = w1.y;
+    uint32_t tm = 0;
+    while (lh) {                                                      // few bits: the hit leaf children
+        const uint32_t s_ = (uint32_t)__builtin_ctz(lh);
+        lh &= lh - 1u;
+        const uint32_t m = ((s_ & 4u) ? w1.w : w1.z) >> (8u * (s_ & 3u));
+        tm |= ((m >> 5) & 7u) << (m & 31u);
+    }
+    trimask = tm;
+}
+
+// a triangle's three packets out of the words a trip loaded (Float32: 3 x uint4, Float64: 6)
+__device__ __forceinline__ void bvh8_tri_words(const uint4 w0, const uint4 w1, const uint4 w2, const uint4, const uint4, const uint4, Pack4<float> &v0, Pack4<float> &e1, Pack4<float> &e2) {
+    v0.x = __uint_as_float(w0.x); v0.y = __uint_as_float(w0.y); v0.z = __uint_as_float(w0.z); v0.w = __uint_as_float(w0.w);
+    e1.x = __uint_as_float(w1.x); e1.y = __uint_as_float(w1.y); e1.z = __uint_as_float(w1.z); e1.w = __uint_as_float(w1.w);
+    e2.x = __uint_as_float(w2.x); e2.y = __uint_as_float(w2.y); e2.z = __uint_as_float(w2.z); e2.w = __uint_as_float(w2.w);
+}
+__device__ __forceinline__ void bvh8_tri_words(const uint4 w0, const uint4 w1, const uint4 w2, const uint4 w3, const uint4 w4, const uint4 w5, Pack4<double> &v0, Pack4<double> &e1, Pack4<double> &e2) {
+    v0.x = __hiloint2double((int)w0.y, (int)w0.x); v0.y = __hiloint2double((int)w0.w, (int)w0.z); v0.z = __hiloint2double((int)w1.y, (int)w1.x); v0.w = __hiloint2double((int)w1.w, (int)w1.z);
+    e1.x = __hiloint2double((int)w2.y, (int)w2.x); e1.y = __hiloint2double((int)w2.w, (int)w2.z); e1.z = __hiloint2double((int)w3.y, (int)w3.x); e1.w = __hiloint2double((int)w3.w, (int)w3.z);
+    e2.x = __hiloint2double((int)w4.y, (int)w4.x); e2.y = __hiloint2double((int)w4.w, (int)w4.z); e2.z = __hiloint2double((int)w5.y, (int)w5.x); e2.w = __hiloint2double((int)w5.w, (int)w5.z);
+}
+
+// start at the root: a group holding only slot 0 (child_base 0, bit 0 ^ oct: slot = bit ^ oct = 0)
+template <class T> __device__ __forceinline__ void bvh8_begin(Bvh8Walk<T> &w, const Bvh8Ray &r, T t0) {
+    w.G = 1u << r.oct; w.trimask = 0; w.tri_base = 0; w.sp = 0; w.t0 = t0;
+}
+
+// One trip of a lane's walk = ONE memory round trip: a lane with triangles pending tests the next one (render precision, caller's
+// coordinates: the scan's own test), any other lane visits its nearest pending child node; both kinds of lane issue their loads
+// together, through one per-lane pointer, before either computes.  (A node visit followed by a loop over its triangles made a wave
+// pay one dependent round trip per triangle of its unluckiest lane: ~10 000 cycles per wave-step on config 5.)  A group that is
+// exhausted pops the stack.  Returns false when the walk is over.  Stack levels < KL live in the wave's LDS scratch ([level][lane]).
+template <class T, int KL>
+__device__ __forceinline__ bool bvh8_step(const SceneLds<T> &sc, Bvh8Walk<T> &w, Bvh8Ray &r, Vec<T> o, Vec<T> d, T t_min, int base, T &closest, int &prim, uint32_t &slot,
+                                          uint32_t *lds_stack, uint32_t *stack, uint32_t lane) {
+    constexpr bool kWide = sizeof(T) == 8;
+    const bool is_tri = w.trimask != 0;
+    const uint4 *ptr;
+    uint32_t ti = 0;
+    if (is_tri) {
+        ti = w.tri_base + (uint32_t)__builtin_ctz(w.trimask);
+        w.trimask &= w.trimask - 1u;
+        ptr = reinterpret_cast<const uint4 *>(sc.bvh_tris + 3 * (size_t)ti);
+    } else {
+        const uint32_t pos = (uint32_t)__builtin_ctz(w.G);                 // (the low byte is never empty here)
+        const uint32_t idx = (w.G >> 8) + (pos ^ r.oct);
+        w.G &= w.G - 1u;
+        if (w.G & 0xFFu) {                                                 // siblings left: keep the group
+            if (KL > 0 && w.sp < KL) lds_stack[w.sp * 64 + lane] = w.G; else stack[w.sp - KL] = w.G;
+            ++w.sp;
+        }
+        ptr = sc.bvh_nodes + 5 * (size_t)idx;
+    }
+    // Every lane loads the same number of words (a node is 5 x 16 bytes, a triangle 3 in Float32 and 6 in Float64; the arrays are padded
+    // by one record): a wave-instruction costs the memory pipeline the same whichever lanes take part, and loads under a condition
+    // would be sunk behind the other arm's arithmetic — a second round trip.  The empty asm pins all of them ahead of both arms.
+    uint4 w0 = ptr[0], w1 = ptr[1], w2 = ptr[2], w3 = ptr[3], w4 = ptr[4], w5 = make_uint4(0, 0, 0, 0);
+    if (kWide) w5 = ptr[5];
+    asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w), "+v"(w2.x), "+v"(w2.y), "+v"(w2.z), "+v"(w2.w));
+    asm volatile("" : "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w), "+v"(w4.x), "+v"(w4.y), "+v"(w4.z), "+v"(w4.w));
+    if (kWide) asm volatile("" : "+v"(w5.x), "+v"(w5.y), "+v"(w5.z), "+v"(w5.w));
+    if (is_tri) {
+        Pack4<T> v0, e1, e2;
+        bvh8_tri_words(w0, w1, w2, w3, w4, w5, v0, e1, e2);
+        T t;
+        if (triangle_test<T>(v0, e1, e2, o, d, t_min, closest, t)) {
+            const int p = base + (int)Bits<T>::to_u32(v0.w);
+            if (t < closest || p > prim) {                                // t == closest: the later object wins
+                closest = t; prim = p; slot = ti;
+                r.best = bvh8_best((float)((t - w.t0) * sc.bvh_root[2].w));
+            }
+        }
+    } else {
+        uint32_t ih, cb;
+        bvh8_node(w0, w1, w2, w3, w4, r, ih, cb, w.trimask, w.tri_base);
+        w.G = (cb << 8) | ih;
+    }
+    if (w.trimask == 0 && !(w.G & 0xFFu)) {
+        if (w.sp == 0) return false;
+        --w.sp;
+        w.G = (KL > 0 && w.sp < KL) ? lds_stack[w.sp * 64 + lane] : stack[w.sp - KL];
+    }
+    return true;
+}
+
+// `closest` / `prim` come in holding the best hit so far (spheres, LDS triangles) and go out updated; `slot` is the hit triangle's
+// position in the reordered array.
 template <class T, int KL = 0>
 __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, uint32_t &slot, uint32_t *lds_stack = nullptr) {
-    const Vec<T> inv = mk<T>(rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z));
-    // most rays of a frame never come near the mesh: its bounding box sits in LDS, and a ray that misses it (same conservative slab
-    // test as for the nodes) is done without a single global-memory access
-    if (box_entry<T>(sc.bvh_root[0], sc.bvh_root[1], o, inv, closest) < (T)0) return;
+    Bvh8Ray r; T t0;
+    if (!bvh8_enter<T>(sc, o, d, closest, r, t0)) return;
+    Bvh8Walk<T> w;
+    bvh8_begin<T>(w, r, t0);
     uint32_t stack[kBvhStackD - KL];
     const uint32_t lane = threadIdx.x & 63;
-    auto push = [&](int level, uint32_t v) { if (KL > 0 && level < KL) lds_stack[level * 64 + lane] = v; else stack[level - KL] = v; };
-    auto pop = [&](int level) -> uint32_t { return (KL > 0 && level < KL) ? lds_stack[level * 64 + lane] : stack[level - KL]; };
-    int sp = 0;
-    uint32_t ref = 0;                                          // root: interior node 0
     const int base = (int)(sc.n_spheres + sc.n_triangles);
-    while (true) {
-        if (ref & kBvhLeafFlagD) {
-            const uint32_t first = ref & 0x00FFFFFFu, cnt = (ref >> 24) & 0x7Fu;
-            for (uint32_t i = first; i < first + cnt; ++i) {
-                const Pack4<T> v0 = sc.bvh_tris[3 * (size_t)i], e1 = sc.bvh_tris[3 * (size_t)i + 1], e2 = sc.bvh_tris[3 * (size_t)i + 2];
-                T t;
-                if (triangle_test<T>(v0, e1, e2, o, d, t_min, closest, t)) {
-                    const int p = base + (int)Bits<T>::to_u32(v0.w);
-                    if (t < closest || p > prim) { closest = t; prim = p; slot = i; }   // t == closest: the later object wins
-                }
-            }
-        } else {
-            const Pack4<T> l0 = sc.bvh_nodes[4 * (size_t)ref], l1 = sc.bvh_nodes[4 * (size_t)ref + 1];
-            const Pack4<T> r0 = sc.bvh_nodes[4 * (size_t)ref + 2], r1 = sc.bvh_nodes[4 * (size_t)ref + 3];
-            const T tl = box_entry<T>(l0, l1, o, inv, closest), tr = box_entry<T>(r0, r1, o, inv, closest);
-            const uint32_t lref = Bits<T>::to_u32(l0.w), rref = Bits<T>::to_u32(r0.w);
-            const bool hl = tl >= (T)0 && lref != kBvhNoneD, hr = tr >= (T)0 && rref != kBvhNoneD;
-            if (hl && hr) {
-                const bool left_first = tl <= tr;
-                push(sp++, left_first ? rref : lref);
-                ref = left_first ? lref : rref;
-                continue;
-            }
-            if (hl) { ref = lref; continue; }
-            if (hr) { ref = rref; continue; }
-        }
-        if (sp == 0) break;
-        ref = pop(--sp);
-    }
+    while (bvh8_step<T, KL>(sc, w, r, o, d, t_min, base, closest, prim, slot, lds_stack, stack, lane)) {}
 }
 
 // Linear scan with a shrinking t_max, examples/julia-raytracer.jl:242-258; spheres :113-142, triangles
@@ -1037,6 +1156,17 @@ template <class T> struct PathArgs {
     uint32_t dense_pct;              // dense continuation threshold in % (0 = always go through the queue)
     Pack4<T> *mesh_list;             // BVH scenes: per wave `cap` entries of 3 packets — rays that reach the mesh's bounding box wait here
                                      // for the end of the round and are traversed as dense batches of 64 (NULL = traverse in place)
+    uint32_t mesh_min_batch;         // parked rays wait (over several rounds if need be) until the wave holds this many — or has nothing else to do
+    uint32_t refill_free;            // a traversal session hands new rays to the free lanes once this many lanes are free
+    // Mesh scenes run a pass as TWO launches (mesh_mode 1 then 2; 0 = one launch, sessions inside it).  Late in a pass a wave of the
+    // first launch holds a handful of mesh rays at best — sessions of 40 rays ran at 0.22 lane utilisation — so the first launch (many
+    // thin waves: all the work that never touches the mesh) only PARKS the rays that reach the mesh's box and lets their paths rest;
+    // the second launch (few fat waves, wave w taking over the lists of first-launch waves w*k .. w*k+k-1) traverses them in large
+    // refilled sessions and carries those paths to their end on its own queue regions.
+    uint32_t mesh_mode;
+    uint32_t *mesh_count;            // [NW of the first launch] parked rays per wave (written by mode 1, read by mode 2)
+    uint32_t resume_k, resume_nw;    // first-launch waves per second-launch wave (<= 16, divides resume_nw), and their total number.  Mode 1 deals
+                                     // its sub-chunks so that the k waves one fat wave takes over work on image blocks far apart (load balance)
     uint32_t *redo;                  // [NW] speculative division (SpecDiv above): the SPEC launch leaves 1 for a wave that has to be rendered again,
     uint32_t redo_only;              // the exact launch behind it (redo_only = 1) renders exactly those waves.  NULL / 0: one exact launch.
     Stats *stats;                    // redo_only: counts the waves rendered again
@@ -1048,6 +1178,15 @@ __device__ __forceinline__ double pack_qref(uint32_t q, uint32_t ref, double) { 
 __device__ __forceinline__ uint32_t unpack_q(float w) { return __float_as_uint(w); }
 __device__ __forceinline__ uint32_t unpack_q(double w) { return (uint32_t)(unsigned long long)__double_as_longlong(w); }
 __device__ __forceinline__ uint32_t unpack_ref(double w) { return (uint32_t)((unsigned long long)__double_as_longlong(w) >> 32); }
+
+#ifdef SPIRA_MESH_STATS
+// experiment builds only (make stats): wave-summed traversal counters, read by spira_debug_mesh_stats()
+// 0 wave cycles, 1 session cycles, 2 sessions, 3 wave-steps, 4 lane-steps, 5 refill blocks, 6 rays traversed, 7 rounds, 8 triangle tests (lane), 9 walk-loop cycles
+__device__ unsigned long long g_mesh_dbg[32];        // [16..31]: the same for the second launch of a mesh pass (mesh_mode 2)
+#define MESH_STAT(...) __VA_ARGS__
+#else
+#define MESH_STAT(...)
+#endif
 
 template <class T, int R, bool BVH, bool EXT, bool SPEC>
 __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const PathArgs<T> a) {
@@ -1077,7 +1216,10 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
         if (lane == 0) atomicAdd(&a.stats->redone_waves, 1ull);
     }
     Pack4<T> *s_rnd = reinterpret_cast<Pack4<T> *>(lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles)) + wave * SUB;
-    const uint32_t region = wid * a.cap;
+    const uint32_t mesh_mode = BVH ? a.mesh_mode : 0u;
+    const uint32_t kseg = mesh_mode == 2u ? a.resume_k : 1u;
+    if (mesh_mode == 2u && wid * kseg >= a.resume_nw) return;    // wave-uniform; no workgroup barrier follows
+    const uint32_t region = wid * kseg * a.cap;                  // (a fat wave owns the regions of the k waves it takes over)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t ref_base = sc.n_spheres + sc.n_triangles;     // references >= ref_base are BVH triangle slots
     // Dense continuation (a.dense_pct > 0, max_depth <= 128; host default 80 % in Float64, 90 % in Float32): when at least dense_pct % of a
@@ -1105,17 +1247,36 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
         C.x = beta_.z; C.y = closest_; C.z = Bits<T>::from_u32(q_); C.w = Bits<T>::from_u32((uint32_t)(prim_ + 1) | (stage_hit << kStageShift));
         mlist[3 * (size_t)slot_i] = A; mlist[3 * (size_t)slot_i + 1] = B; mlist[3 * (size_t)slot_i + 2] = C;
     };
-    const uint32_t n_rounds = defer ? rc.max_depth + 1 : rc.max_depth;      // a parked camera ray is shaded one round later
-    for (uint32_t round = 0; round < n_rounds; ++round) {
+    // Rounds: every packet of the wave's queue advances one stage per round; parked rays re-enter as hit packets after a traversal
+    // session, possibly several rounds after they were parked (packets carry their own stage).  Ends when queue and list are empty.
+    uint32_t mfill = 0;                                              // entries on the mesh list
+    // mode 2: the list starts as the k lists the first launch left, segment j at its wave's region; pfx[j] = entries ahead of segment j
+    constexpr int kMaxSeg = 16;
+    uint32_t pfx[kMaxSeg + 1];
+    bool segmented = false;
+    {
+        uint32_t cnt = 0;
+        if (mesh_mode == 2u && lane < kseg && wid * kseg + lane < a.resume_nw) cnt = a.mesh_count[wid * kseg + lane];
+        pfx[0] = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxSeg; ++j) pfx[j + 1] = pfx[j] + (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+        if (mesh_mode == 2u) { mfill = pfx[kMaxSeg]; segmented = true; }
+    }
+    // Mode 1: wave w*k + i works on the sub-chunks of "logical" wave i*(NW/k) + w, so that the k waves a fat wave of the second launch takes over
+    // (w*k .. w*k+k-1: contiguous regions) cover image blocks NW/k sub-chunks apart — adjacent blocks see the mesh together or not at all, and
+    // fat waves made of them ran 1.5x apart.  (Any bijection will do: the assignment only has to be a pure function of the wave index.)
+    const uint32_t first_sub = mesh_mode == 1u ? (wid % a.resume_k) * (NW / a.resume_k) + wid / a.resume_k : wid;
+    MESH_STAT(unsigned long long dbg_t0 = __builtin_readcyclecounter(); unsigned long long dbg_sess = 0, dbg_walk = 0; uint32_t dbg_ns = 0, dbg_ws = 0, dbg_ls = 0, dbg_rf = 0, dbg_rays = 0, dbg_rounds = 0, dbg_ws1 = 0, dbg_ls1 = 0, dbg_h[4] = {0, 0, 0, 0};)
+    for (uint32_t round = 0; ; ++round) {
+        MESH_STAT(++dbg_rounds;)
         const bool first = round == 0;
-        uint32_t mfill = 0;                                          // entries on the mesh list this round
         const RayQueue<T> qin = a.q[(round + 1) & 1], qout = a.q[round & 1];
         const uint32_t *rin = a.qref[(round + 1) & 1];
         uint32_t *rout = a.qref[round & 1];
         const uint32_t limit = first ? a.n_first : n_in;
         const uint32_t n_sub = first ? n_sub_first : (n_in + SUB - 1) / SUB;
         uint32_t fill = 0;
-        for (uint32_t sub = first ? wid : 0u; sub < n_sub; sub += first ? NW : 1u) {
+        for (uint32_t sub = first ? first_sub : 0u; sub < n_sub; sub += first ? NW : 1u) {
             Vec<T> o[R], beta[R];
             Pending<T> pend[R];                           // between trips pend[r].v holds the direction the hit was reached along
             ExtState<T> ex[R];                            // EXT instantiations only (dead otherwise)
@@ -1328,26 +1489,27 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                 break;
             }
         }
-        if (defer && mfill) {
-            // ---------------- the round's parked rays: dense batches of 64 through the tree (the work list's LDS is idle now: stack levels)
+        if (defer && mesh_mode != 1u && mfill && (mfill >= a.mesh_min_batch || fill == 0)) {
+            // ---------------- traversal session over the wave's parked rays.  A divergent node fetch costs the CU the same whether 64 lanes
+            // take part or one (profiles/r03_gather_chase.txt), so the wave is kept full: whenever `refill_free` lanes have finished their
+            // ray, their results are emitted (hits compacted into the out queue, sky terms for the others) and they take the next parked
+            // rays; only the list's last rays run down to the slowest.  (The work list's LDS is idle now: the first stack levels live there.)
             constexpr int kLdsStack = (int)(SUB * sizeof(Pack4<T>) / (64 * sizeof(uint32_t)));      // 8 levels in Float32, 16 in Float64
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the list was written by this wave's own lanes
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            for (uint32_t base = 0; base < mfill; base += 64) {
-                const uint32_t e = base + lane;
-                bool hit = false;
-                Vec<T> o_ = mk<T>(0, 0, 0), d_ = mk<T>(0, 0, 1), beta_ = mk<T>(0, 0, 0);
-                uint32_t q_ = 0, w_ = 0;
-                if (e < mfill) {
-                    const Pack4<T> A = mlist[3 * (size_t)e], B = mlist[3 * (size_t)e + 1], C = mlist[3 * (size_t)e + 2];
-                    o_ = mk<T>(A.x, A.y, A.z); d_ = mk<T>(A.w, B.x, B.y); beta_ = mk<T>(B.z, B.w, C.x);
-                    T closest = C.y;
-                    q_ = Bits<T>::to_u32(C.z);
-                    const uint32_t pw = Bits<T>::to_u32(C.w);
-                    int prim = (int)(pw & kRefMask) - 1;
-                    const uint32_t stage_hit = pw >> kStageShift;
-                    uint32_t slot = 0;
-                    bvh_closest_hit<T, kLdsStack>(sc, o_, d_, (T)0.001, closest, prim, slot, reinterpret_cast<uint32_t *>(s_rnd));
+            uint32_t *lstack = reinterpret_cast<uint32_t *>(s_rnd);
+            uint32_t stack[kBvhStackD - kLdsStack];
+            uint32_t next = 0;                                         // next unread entry (wave-uniform)
+            MESH_STAT(const unsigned long long dbg_s0 = __builtin_readcyclecounter(); ++dbg_ns; dbg_rays += mfill;)
+            bool walking = false, finished = false;                    // finished: a result waits to be emitted
+            Vec<T> o_ = mk<T>(0, 0, 0), d_ = mk<T>(0, 0, 1), beta_ = mk<T>(0, 0, 0);
+            T closest = 0; uint32_t q_ = 0, stage_hit = 0, slot = 0; int prim = -1;
+            Bvh8Ray ry; ry.ox = ry.oy = ry.oz = 0; ry.ix = ry.iy = ry.iz = 1; ry.oct = 0; ry.best = 0;
+            Bvh8Walk<T> wk; wk.G = 0; wk.trimask = 0; wk.tri_base = 0; wk.sp = 0; wk.t0 = 0;
+            while (true) {
+                // ---- emit what is finished, refill the free lanes (wave-uniform block)
+                const unsigned long long mh = __ballot(finished && prim >= 0);
+                if (finished) {
                     if (prim < 0) {                                   // the ray leaves the scene after all: sky, :365-366
                         const uint32_t qi = q_ & 0x7FFFFFFFu;
                         ExtState<T> ex1; ex1.flags = rc.flags; ex1.bR = 0; ex1.bG = 0; ex1.bB = 0;
@@ -1362,27 +1524,62 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         else ++n_store;
                         a.L[qi] = l;
                     } else {
-                        hit = true;
-                        o_ = o_ + d_ * closest;                       // point_at, :138 / :183
-                        w_ = ((prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim) | (stage_hit << kStageShift);
+                        const Vec<T> hp = o_ + d_ * closest;          // point_at, :138 / :183
+                        const uint32_t w_ = ((prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim) | (stage_hit << kStageShift);
+                        const uint32_t dst = region + fill + __popcll(mh & lt_mask);
+                        Pack4<T> A, B; Pack2<T> C;
+                        A.x = hp.x; A.y = hp.y; A.z = hp.z; A.w = d_.x;
+                        B.x = d_.y; B.y = d_.z; B.z = beta_.x; B.w = beta_.y;
+                        C.x = beta_.z; C.y = pack_qref(q_, w_, (T)0);
+                        qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
+                        if constexpr (kRefArray) rout[dst] = w_;
                     }
                 }
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const uint32_t dst = region + fill + __popcll(m & lt_mask);
-                    Pack4<T> A, B; Pack2<T> C;
-                    A.x = o_.x; A.y = o_.y; A.z = o_.z; A.w = d_.x;
-                    B.x = d_.y; B.y = d_.z; B.z = beta_.x; B.w = beta_.y;
-                    C.x = beta_.z; C.y = pack_qref(q_, w_, (T)0);
-                    qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
-                    if constexpr (kRefArray) rout[dst] = w_;
+                fill += (uint32_t)__popcll(mh);
+                finished = false;
+                const unsigned long long mf = __ballot(!walking);
+                const uint32_t take = min((uint32_t)__popcll(mf), mfill - next);
+                if (!walking && (uint32_t)__popcll(mf & lt_mask) < take) {
+                    const uint32_t e = next + (uint32_t)__popcll(mf & lt_mask);
+                    const Pack4<T> *ent = mlist + 3 * (size_t)e;
+                    if (segmented) {                               // entry e of the k lists taken over: which list, which entry of it
+                        uint32_t seg = 0, off = e;
+#pragma unroll
+                        for (int j = 1; j < kMaxSeg; ++j) if (e >= pfx[j]) { seg = (uint32_t)j; off = e - pfx[j]; }
+                        ent = a.mesh_list + 3 * ((size_t)(wid * kseg + seg) * a.cap + off);
+                    }
+                    const Pack4<T> A = ent[0], B = ent[1], C = ent[2];
+                    o_ = mk<T>(A.x, A.y, A.z); d_ = mk<T>(A.w, B.x, B.y); beta_ = mk<T>(B.z, B.w, C.x);
+                    closest = C.y;
+                    q_ = Bits<T>::to_u32(C.z);
+                    const uint32_t pw = Bits<T>::to_u32(C.w);
+                    prim = (int)(pw & kRefMask) - 1;
+                    stage_hit = pw >> kStageShift;
+                    slot = 0;
+                    T t0;
+                    if (bvh8_enter<T>(sc, o_, d_, closest, ry, t0)) { bvh8_begin<T>(wk, ry, t0); walking = true; }
+                    else finished = true;
                 }
-                fill += (uint32_t)__popcll(m);
+                next += take;
+                if (!__any(walking)) { if (__any(finished)) continue; break; }
+                // ---- walk; leave the loop when enough lanes are free for a refill to pay (or, with the list exhausted, when all are done)
+                const bool more = next < mfill;
+                MESH_STAT(++dbg_rf; const unsigned long long dbg_w0 = __builtin_readcyclecounter();)
+                while (true) {
+                    MESH_STAT(++dbg_ws; { const uint32_t nl = (uint32_t)__popcll(__ballot(walking)); dbg_ls += nl; if (segmented) { ++dbg_ws1; dbg_ls1 += nl; } ++dbg_h[nl <= 8 ? 0 : (nl <= 24 ? 1 : (nl <= 48 ? 2 : 3))]; })
+                    if (walking && !bvh8_step<T, kLdsStack>(sc, wk, ry, o_, d_, (T)0.001, (int)ref_base, closest, prim, slot, lstack, stack, lane)) { walking = false; finished = true; }
+                    const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+                    if (n_walk == 0 || (more && 64u - n_walk >= a.refill_free)) break;
+                }
+                MESH_STAT(dbg_walk += __builtin_readcyclecounter() - dbg_w0;)
             }
+            mfill = 0;
+            segmented = false;                                         // from here on the list is the wave's own (the lists taken over are spent)
+            MESH_STAT(dbg_sess += __builtin_readcyclecounter() - dbg_s0;)
         }
         n_in = fill;
         n_enq += fill;
-        if (n_in == 0) break;              // wave-uniform: every path of this wave has ended
+        if (n_in == 0 && (mfill == 0 || mesh_mode == 1u)) break;      // wave-uniform: every path of this wave has ended (mode 1: or rests on the list)
         // The wave now reads what its own lanes have just written: on one CU (one vector L1, one L2) a workgroup-scope
         // release/acquire (wait for the stores) is all that takes.  No other wave ever touches this region.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1390,11 +1587,22 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     }
     for (int sft = 32; sft > 0; sft >>= 1) { n_rmw += __shfl_down(n_rmw, sft); n_seg += __shfl_down(n_seg, sft); n_store += __shfl_down(n_store, sft); }
     const bool again = SPEC && __any(outside_window<T>(pol));    // some quotient of this wave may not be the IEEE one: the exact launch redoes the wave
+    MESH_STAT(if (lane == 0) { unsigned long long *g = g_mesh_dbg + (mesh_mode == 2u ? 16 : 0);
+                               atomicAdd(&g[0], __builtin_readcyclecounter() - dbg_t0); atomicAdd(&g[1], dbg_sess); atomicAdd(&g[2], (unsigned long long)dbg_ns);
+                               atomicAdd(&g[3], (unsigned long long)dbg_ws); atomicAdd(&g[4], (unsigned long long)dbg_ls); atomicAdd(&g[5], (unsigned long long)dbg_rf);
+                               atomicAdd(&g[6], (unsigned long long)dbg_rays); atomicAdd(&g[7], (unsigned long long)dbg_rounds); atomicAdd(&g[9], dbg_walk); atomicAdd(&g[10], 1ull); atomicAdd(&g[11], (unsigned long long)dbg_ws1); atomicAdd(&g[12], (unsigned long long)dbg_ls1);
+                               atomicAdd(&g[8], (unsigned long long)dbg_h[0]); atomicAdd(&g[13], (unsigned long long)dbg_h[1]); atomicAdd(&g[14], (unsigned long long)dbg_h[2]); atomicAdd(&g[15], (unsigned long long)dbg_h[3]); })
     if (lane == 0) {
-        a.blk_stats[4 * wid] = n_seg;
-        a.blk_stats[4 * wid + 1] = n_rmw;
-        a.blk_stats[4 * wid + 2] = n_store;
-        a.blk_stats[4 * wid + 3] = n_enq;          // wave-uniform
+        if (mesh_mode == 2u) {                     // on top of what the first launch's wave left in the row
+            const uint32_t row = 4 * wid * kseg;
+            a.blk_stats[row] += n_seg; a.blk_stats[row + 1] += n_rmw; a.blk_stats[row + 2] += n_store; a.blk_stats[row + 3] += n_enq;
+        } else {
+            a.blk_stats[4 * wid] = n_seg;
+            a.blk_stats[4 * wid + 1] = n_rmw;
+            a.blk_stats[4 * wid + 2] = n_store;
+            a.blk_stats[4 * wid + 3] = n_enq;          // wave-uniform
+            if (mesh_mode == 1u) a.mesh_count[wid] = mfill;
+        }
         if (SPEC) a.redo[wid] = again ? 1u : 0u;
     }
 }

@@ -63,7 +63,7 @@ struct DevBuf {
 struct SceneStore {
     DevBuf arrays, bvh_nodes, bvh_tris;
     uint32_t ns = 0, nm = 0, nt = 0;
-    uint64_t bvh_hash = 0; uint32_t bvh_n = 0; int bvh_prec = 0, bvh_depth = 0;
+    uint64_t bvh_hash = 0; uint32_t bvh_n = 0, bvh_slots = 0; int bvh_prec = 0, bvh_depth = 0;
     bool moderate = false;                    // every coordinate / radius of ordinary magnitude (spira::scene_scale_moderate): speculative division pays
     void release() { arrays.release(); bvh_nodes.release(); bvh_tris.release(); bvh_hash = 0; bvh_n = 0; }
 };
@@ -73,7 +73,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], mesh_list, redo, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], mesh_list, mesh_count, redo, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
     DevBuf spd32, spd64;                          // SPIRA_EXT_SPECTRAL: the SPD table, uploaded once per precision
     DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
     SceneStore scene;                         // the scene of the current call (host-array entry points)
@@ -232,9 +232,11 @@ void scene_pointers(const SceneStore &s, spira::SceneGlobal<T> &g) {
     g.materials8 = (const T *)(base + up(ns_b));
     g.triangles10 = (const T *)(base + up(ns_b) + up(nm_b));
     g.n_spheres = s.ns; g.n_materials = s.nm; g.n_triangles = nt_lds;
-    g.bvh_nodes = use_bvh ? (const spira::Pack4<T> *)s.bvh_nodes.p : nullptr;
-    g.bvh_tris = use_bvh ? (const spira::Pack4<T> *)s.bvh_tris.p : nullptr;
+    g.bvh_nodes = use_bvh ? (const uint4 *)s.bvh_nodes.p : nullptr;
+    g.bvh_frame = use_bvh ? (const spira::Pack4<T> *)s.bvh_tris.p : nullptr;          // 3 packets ahead of the triangles
+    g.bvh_tris = use_bvh ? (const spira::Pack4<T> *)s.bvh_tris.p + 3 : nullptr;
     g.n_bvh_tris = use_bvh ? s.nt : 0;
+    g.bvh_slots = use_bvh ? s.bvh_slots : 0;
 }
 
 // Upload host arrays into `s`.  The small arrays go asynchronously on `st`; a mesh above SPIRA_LDS_TRIANGLES gets a
@@ -258,16 +260,23 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
     if (use_bvh) {
         const uint64_t h = spira::bytes_hash64(triangles10, (size_t)nt * 10 * sizeof(T));
         if (s.bvh_hash != h || s.bvh_n != nt || s.bvh_prec != (int)sizeof(T)) {
-            std::vector<spira::HostPack4<T>> nodes, tris;
-            int depth = 0;
-            if (!spira::bvh_build<T>(triangles10, nt, nodes, tris, &depth)) return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
+            std::vector<uint32_t> nodes;
+            std::vector<spira::HostPack4<T>> tris;
+            spira::BvhFrame<T> fr{};
+            if (!spira::bvh_build<T>(triangles10, nt, nodes, tris, fr, std::min<uint32_t>(spira::kBvhLeafTris, std::max<uint32_t>(1, env_u32("SPIRA_BVH_LEAF", 1))))) return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
+            const spira::HostPack4<T> frame[3] = {{fr.root_mn[0], fr.root_mn[1], fr.root_mn[2], (T)0}, {fr.root_mx[0], fr.root_mx[1], fr.root_mx[2], (T)0},
+                                                  {fr.centre[0], fr.centre[1], fr.centre[2], fr.scale}};
             if (prev_done) HIP_TRY(hipEventSynchronize(prev_done));      // nobody still reads the tree that is about to be replaced
-            if (int rc = s.bvh_nodes.ensure(nodes.size() * sizeof(nodes[0]))) return rc;
-            if (int rc = s.bvh_tris.ensure(tris.size() * sizeof(tris[0]))) return rc;
+            // (+ one record of padding each: a walk's trip loads 5 / 6 x 16 bytes from a node or a triangle alike, spira_device.h bvh8_step)
+            if (int rc = s.bvh_nodes.ensure(nodes.size() * sizeof(nodes[0]) + 128)) return rc;
+            if (int rc = s.bvh_tris.ensure(sizeof frame + tris.size() * sizeof(tris[0]) + 128)) return rc;
             // synchronous copies: the host vectors die at the end of this scope
             HIP_TRY(hipStreamSynchronize(st));
             HIP_TRY(hipMemcpy(s.bvh_nodes.p, nodes.data(), nodes.size() * sizeof(nodes[0]), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(s.bvh_tris.p, tris.data(), tris.size() * sizeof(tris[0]), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(s.bvh_tris.p, frame, sizeof frame, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy((char *)s.bvh_tris.p + sizeof frame, tris.data(), tris.size() * sizeof(tris[0]), hipMemcpyHostToDevice));
+            const int depth = fr.depth;
+            s.bvh_slots = fr.n_slots;
             s.bvh_hash = h; s.bvh_n = nt; s.bvh_prec = (int)sizeof(T); s.bvh_depth = depth;
         }
     }
@@ -275,10 +284,21 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
 }
 
 // Launch with a dynamic LDS block; above 64 KB the function has to be told first (up to the CU's 160 KB).
+// A refused opt-in is remembered (thread-local) and turned into SPIRA_E_LIMIT by lds_optin_failed() before the call returns.
+thread_local hipError_t tl_lds_optin = hipSuccess;
 template <class K, class... Args>
 void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { tl_lds_optin = e; return; }          // do not launch a kernel that cannot get its LDS
+    }
     hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
+int lds_optin_failed() {
+    if (tl_lds_optin == hipSuccess) return 0;
+    const hipError_t e = tl_lds_optin;
+    tl_lds_optin = hipSuccess;
+    return fail(SPIRA_E_LIMIT, std::string("the device refused the kernel's dynamic LDS size (hipFuncSetAttribute): ") + hipGetErrorString(e));
 }
 
 template <class T, bool FIRST, bool BVH>
@@ -323,6 +343,18 @@ int launch_path(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathArgs<T>
         if (bvh) launch_lds(spira::k_path<T, 1, true, false, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 1, false, false, false>, grid, blk, lds, st, a);
     }
     return 0;
+}
+
+// the second launch of a mesh pass (PathArgs::mesh_mode 2): the exact instantiation — its waves add to radiance the first launch
+// already stored, so they could not be rendered again, and its divisions are a small share of the frame's
+template <class T>
+void launch_path_resume(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathArgs<T> a) {
+    const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
+    const dim3 blk(spira::kBlock);
+    a.redo = nullptr; a.redo_only = 0;
+    if (ext) launch_lds(spira::k_path<T, 2, true, true, false>, grid, blk, lds, st, a);
+    else if (R == 2) launch_lds(spira::k_path<T, 2, true, false, false>, grid, blk, lds, st, a);
+    else launch_lds(spira::k_path<T, 1, true, false, false>, grid, blk, lds, st, a);
 }
 
 int profile_events(Ctx &c, size_t need) {
@@ -436,7 +468,8 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     // f32 32 per CU 7.54 ms, 16: 6.78, 8: 7.29, 4: 7.04; f64 32: 11.67, 8: 10.29, 4: 9.68; re-measured with the round's final kernels: f32 16: 6.83, 8: 7.02, 32: 7.39,
     // f64 4: 9.54, 8: 10.13, 16: 10.49 — and counts that are not powers of two lose 10-40 %: the grid no longer divides evenly over 8 XCDs x 32 CUs).
     const uint32_t nt_scene = h ? h->store.nt : (triangles10 ? p->n_triangles : 0);
-    const uint32_t blocks_per_cu = !persistent ? 16 : (nt_scene > SPIRA_LDS_TRIANGLES ? (sizeof(T) == 8 ? 4 : 16) : 32);
+    const bool mesh_two_pass = persistent && nt_scene > SPIRA_LDS_TRIANGLES && p->max_depth <= 128 && env_u32("SPIRA_DEFER_MESH", 1) && env_u32("SPIRA_MESH_TWO_PASS", 1);
+    const uint32_t blocks_per_cu = !persistent ? 16 : ((nt_scene > SPIRA_LDS_TRIANGLES && !mesh_two_pass) ? 4 : 32);
     const uint32_t max_blocks = (uint32_t)c.num_cus * env_u32("SPIRA_BLOCKS_PER_CU", blocks_per_cu);
     const uint32_t wpb = spira::kBlock / 64;
     const uint32_t sub = 64 * R;                                   // rays per wave sub-chunk
@@ -646,11 +679,30 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                     if (int rc = c.redo.ensure((size_t)G_max * wpb * sizeof(uint32_t))) return rc;
                     pa.redo = (uint32_t *)c.redo.p;
                 }
-                const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4) + 128;       // + one work list per wave + the camera
+                pa.mesh_mode = 0; pa.mesh_count = nullptr; pa.resume_k = 1; pa.resume_nw = 0;
+                pa.mesh_min_batch = std::max<uint32_t>(1, env_u32("SPIRA_MESH_MIN_BATCH", 128));
+                pa.refill_free = std::min<uint32_t>(64, std::max<uint32_t>(1, env_u32("SPIRA_MESH_REFILL", 16)));
+                const size_t lds_a = lds + (size_t)wpb * sub * sizeof(P4) + 128;       // + one work list per wave + the camera
+                if (mesh_two_pass && pa.mesh_list) {
+                    if (int rc = c.mesh_count.ensure((size_t)G_max * wpb * sizeof(uint32_t))) return rc;
+                    pa.mesh_mode = 1; pa.mesh_count = (uint32_t *)c.mesh_count.p;
+                    // the fat waves of the second launch: about 16 per CU (4 per SIMD), each taking over k <= 16 first-launch waves; k divides their number
+                    const uint32_t nw = G * wpb, fat = std::max<uint32_t>(1, (uint32_t)c.num_cus * env_u32("SPIRA_MESH_FAT_WAVES_PER_CU", 16));
+                    uint32_t k = 16;
+                    while (k > 1 && (nw % k != 0 || nw / k < fat)) k >>= 1;
+                    pa.resume_k = k; pa.resume_nw = nw;
+                }
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
-                if (int rc = launch_path<T>(R, dim3(G), lds_b, st, pa, spec)) return rc;
-                HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
+                if (int rc = launch_path<T>(R, dim3(G), lds_a, st, pa, spec)) return rc;
                 launches += (spec && R == 2) ? 2 : 1;      // the speculative launch and its exact follow-up
+                if (pa.mesh_mode == 1) {           // second launch: nw / k fat waves
+                    spira::PathArgs<T> pb = pa;
+                    pb.mesh_mode = 2; pb.n_first = 0;
+                    const uint32_t nwb = pa.resume_nw / pa.resume_k;
+                    launch_path_resume<T>(R, dim3((nwb + wpb - 1) / wpb), lds_a, st, pb);
+                    ++launches;
+                }
+                HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
             } else {
                 geometry(n_first, G, a.cap);
                 stat_rows = p->max_depth * G * wpb;
@@ -690,6 +742,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     }
     if (progressive && rng_states && !out_on_device)
         HIP_TRY(hipMemcpyAsync(rng_states, d_rng, tile_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    if (int rc = lds_optin_failed()) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c.ev_stop, st));
     HIP_TRY(hipMemcpyAsync(c.h_stats, c.stats.p, sizeof(spira::Stats), hipMemcpyDeviceToHost, st));
@@ -760,6 +813,7 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
         if (a.scene.n_bvh_tris) { if (ext) launch_lds(spira::k_trace<T, true, true>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); else launch_lds(spira::k_trace<T, true, false>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); }
         else { if (ext) launch_lds(spira::k_trace<T, false, true>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); else launch_lds(spira::k_trace<T, false, false>, tg, tb, lds, st, a, d_ij, n_paths, d_pr, d_ts, d_di, d_ra); }
     }
+    if (int rc = lds_optin_failed()) return rc;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(prims, d_pr, nseg * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(ts, d_ts, nseg * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -1043,6 +1097,16 @@ int spira_set_device(int device) {
     return 0;
 }
 
+#ifdef SPIRA_MESH_STATS
+// experiment builds only (make stats; not part of include/spira_hip.h): the traversal counters of spira_device.h, optionally reset
+extern "C" int spira_debug_mesh_stats(unsigned long long *out32, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out32 && hipMemcpyFromSymbol(out32, HIP_SYMBOL(spira::g_mesh_dbg), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(spira::g_mesh_dbg), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 int spira_get_counters(spira_counters *out) {
     if (!out) return fail(SPIRA_E_INVALID, "out is NULL");
     Ctx *cp = nullptr;
@@ -1083,7 +1147,7 @@ void spira_shutdown(void) {
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qX[i].release(); }
-        c.mesh_list.release();
+        c.mesh_list.release(); c.mesh_count.release();
         c.redo.release(); c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();

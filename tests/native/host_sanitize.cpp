@@ -2,8 +2,9 @@
 // GPU AddressSanitizer is not available on the pool, so everything of the product that runs on the HOST is exercised here
 // under ASan + UBSan: the BVH builder (spira_bvh.h) over degenerate meshes, the scene validation (spira_validate.h), the
 // magic-number division (spira_fastdiv.h) and the triangle hash; the CPU oracle is linked in and run under the sanitizers too.
-// The tree is checked semantically: a host traversal with the kernels' rules (ordered descent, conservative slab test, leaf =
-// Moller-Trumbore, ties to the later triangle) must return exactly what a linear scan over the caller's array returns.
+// The tree is checked semantically: a host traversal with the kernels' rules (8-wide quantised nodes, Float32 slab tests in the mesh's
+// normalised frame, octant-ordered descent, leaf = Moller-Trumbore in T, ties to the later triangle) must return exactly what a
+// linear scan over the caller's array returns.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -53,64 +54,100 @@ template <class T> static uint32_t bits_of(T w) {
     uint64_t u; std::memcpy(&u, &w, 8); return (uint32_t)u;
 }
 
+// Host mirror of the kernels' walk (spira_device.h: bvh8_enter / bvh8_node / bvh8_step): root box in T, child boxes in Float32 in the
+// normalised frame with 1/d clamped to 2^40, hit children in ascending (slot ^ octant) order, triangles in T on the caller's coordinates.
+struct Stats8 { uint64_t nodes = 0, tris = 0; int max_sp = 0; };
 template <class T>
-static void traverse(const std::vector<spira::HostPack4<T>> &nodes, const std::vector<spira::HostPack4<T>> &tris, V<T> o, V<T> d, T t_min, T &closest, int &prim) {
+static void traverse(const std::vector<uint32_t> &nodes, const std::vector<spira::HostPack4<T>> &tris, const spira::BvhFrame<T> &fr, V<T> o, V<T> d, T t_min,
+                     T &closest, int &prim, Stats8 &st) {
     const V<T> inv = {(T)1 / d.x, (T)1 / d.y, (T)1 / d.z};
-    auto entry = [&](const spira::HostPack4<T> &mn, const spira::HostPack4<T> &mx) -> T {
-        T x1 = (mn.x - o.x) * inv.x, x2 = (mx.x - o.x) * inv.x, y1 = (mn.y - o.y) * inv.y, y2 = (mx.y - o.y) * inv.y, z1 = (mn.z - o.z) * inv.z, z2 = (mx.z - o.z) * inv.z;
+    T te;
+    {
+        T x1 = (fr.root_mn[0] - o.x) * inv.x, x2 = (fr.root_mx[0] - o.x) * inv.x, y1 = (fr.root_mn[1] - o.y) * inv.y, y2 = (fr.root_mx[1] - o.y) * inv.y,
+          z1 = (fr.root_mn[2] - o.z) * inv.z, z2 = (fr.root_mx[2] - o.z) * inv.z;
         T en = std::fmax(std::fmax(std::fmin(x1, x2), std::fmin(y1, y2)), std::fmin(z1, z2));
         T ex = std::fmin(std::fmin(std::fmax(x1, x2), std::fmax(y1, y2)), std::fmax(z1, z2));
-        return (en <= ex && ex >= 0 && en <= closest) ? std::fmax(en, (T)0) : (T)-1;
-    };
+        if (!(en <= ex && ex >= 0 && en <= closest)) return;
+        te = std::fmax(en, (T)0);
+    }
+    const float ox = (float)(((o.x + d.x * te) - fr.centre[0]) * fr.scale), oy = (float)(((o.y + d.y * te) - fr.centre[1]) * fr.scale),
+                oz = (float)(((o.z + d.z * te) - fr.centre[2]) * fr.scale);
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    const bool ng[3] = {dx < 0, dy < 0, dz < 0};
+    const uint32_t oct = (ng[0] ? 1u : 0u) | (ng[1] ? 2u : 0u) | (ng[2] ? 4u : 0u);
+    auto rcp = [](float x, bool neg) { float a = std::fmax(std::fabs(x), std::ldexp(1.0f, -spira::kBvhInvClampExp)); return neg ? -1.0f / a : 1.0f / a; };
+    const float iv[3] = {rcp(dx, ng[0]), rcp(dy, ng[1]), rcp(dz, ng[2])}, on[3] = {ox, oy, oz};
+    float best = (float)((closest - te) * fr.scale) * 1.00000095367431640625f;
     uint32_t stack[spira::kBvhStack];
     int sp = 0;
-    uint32_t ref = 0;
+    uint32_t G = 1u << oct;
     while (true) {
-        if (ref & spira::kBvhLeafFlag) {
-            uint32_t first = ref & 0x00FFFFFFu, cnt = (ref >> 24) & 0x7Fu;
-            CHECK(cnt >= 1 && cnt <= spira::kBvhMaxLeaf && (size_t)(first + cnt) * 3 <= tris.size());
-            for (uint32_t i = first; i < first + cnt; ++i) {
-                const auto &a = tris[3 * (size_t)i], &b = tris[3 * (size_t)i + 1], &c = tris[3 * (size_t)i + 2];
-                T t;
-                if (tri_test<T>({a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}, o, d, t_min, closest, t)) {
-                    int p = (int)bits_of(a.w);
-                    if (t < closest || p > prim) { closest = t; prim = p; }
-                }
+        const uint32_t pos = (uint32_t)__builtin_ctz(G), idx = (G >> 8) + (pos ^ oct);
+        G &= G - 1u;
+        if (G & 0xFFu) { CHECK(sp < spira::kBvhStack); stack[sp++] = G; st.max_sp = std::max(st.max_sp, sp); }
+        CHECK(idx < fr.n_slots);
+        const uint32_t *w = &nodes[(size_t)idx * spira::kBvhNodeDwords];
+        ++st.nodes;
+        const uint32_t imask = w[3] >> 24;
+        uint32_t hits = 0;
+        for (int i = 0; i < 8; ++i) {
+            float tn = 0.0f, tf = best;
+            for (int k = 0; k < 3; ++k) {
+                const float step = spira::bits_float(((w[3] >> (8 * k)) & 0xFFu) << 23);
+                const float a = step * iv[k], b = (spira::bits_float(w[k]) - on[k]) * iv[k];
+                const uint32_t lo = (w[8 + 2 * k + (i >> 2)] >> (8 * (i & 3))) & 0xFFu, hi = (w[14 + 2 * k + (i >> 2)] >> (8 * (i & 3))) & 0xFFu;
+                const float tnk = std::fmaf((float)(ng[k] ? hi : lo), a, b), tfk = std::fmaf((float)(ng[k] ? lo : hi), a, b);
+                tn = std::fmax(tn, tnk); tf = std::fmin(tf, tfk);
             }
-        } else {
-            CHECK((size_t)ref * 4 + 3 < nodes.size());
-            const auto &l0 = nodes[4 * (size_t)ref], &l1 = nodes[4 * (size_t)ref + 1], &r0 = nodes[4 * (size_t)ref + 2], &r1 = nodes[4 * (size_t)ref + 3];
-            T tl = entry(l0, l1), tr = entry(r0, r1);
-            uint32_t lref = bits_of(l0.w), rref = bits_of(r0.w);
-            bool hl = tl >= 0 && lref != spira::kBvhNone, hr = tr >= 0 && rref != spira::kBvhNone;
-            if (hl && hr) { bool lf = tl <= tr; CHECK(sp < spira::kBvhStack); stack[sp++] = lf ? rref : lref; ref = lf ? lref : rref; continue; }
-            if (hl) { ref = lref; continue; }
-            if (hr) { ref = rref; continue; }
+            if (tn <= tf) hits |= 1u << i;
         }
-        if (sp == 0) break;
-        ref = stack[--sp];
+        uint32_t ih = 0, lh = hits & ~imask;
+        for (int sl = 0; sl < 8; ++sl) if (hits & imask & (1u << sl)) ih |= 1u << (sl ^ oct);
+        G = (w[4] << 8) | ih;
+        uint32_t tm = 0;
+        for (int sl = 0; sl < 8; ++sl)
+            if (lh & (1u << sl)) { const uint32_t m = (w[6 + (sl >> 2)] >> (8 * (sl & 3))) & 0xFFu; tm |= ((m >> 5) & 7u) << (m & 31u); }
+        while (tm) {
+            const uint32_t i = w[5] + (uint32_t)__builtin_ctz(tm);
+            tm &= tm - 1u;
+            CHECK((size_t)i * 3 + 2 < tris.size());
+            const auto &a = tris[3 * (size_t)i], &b = tris[3 * (size_t)i + 1], &c = tris[3 * (size_t)i + 2];
+            T t;
+            ++st.tris;
+            if (tri_test<T>({a.x, a.y, a.z}, {b.x, b.y, b.z}, {c.x, c.y, c.z}, o, d, t_min, closest, t)) {
+                int p = (int)bits_of(a.w);
+                if (t < closest || p > prim) { closest = t; prim = p; best = (float)((t - te) * fr.scale) * 1.00000095367431640625f; }
+            }
+        }
+        if (!(G & 0xFFu)) { if (sp == 0) break; G = stack[--sp]; }
     }
 }
 
 template <class T>
 static void check_mesh(const char *name, const std::vector<T> &t10, uint32_t n_rays, uint32_t seed) {
     const uint32_t n = (uint32_t)(t10.size() / 10);
-    std::vector<spira::HostPack4<T>> nodes, tris;
-    int depth = 0;
-    const bool ok = spira::bvh_build<T>(t10.data(), n, nodes, tris, &depth);
+    std::vector<uint32_t> nodes;
+    std::vector<spira::HostPack4<T>> tris;
+    spira::BvhFrame<T> fr{};
+    const bool ok = spira::bvh_build<T>(t10.data(), n, nodes, tris, fr);
     CHECK(ok);
     if (!ok) return;
-    CHECK(tris.size() == 3 * (size_t)n && nodes.size() >= 4 && nodes.size() % 4 == 0 && depth < spira::kBvhStack - 2);
+    CHECK(tris.size() == 3 * (size_t)n && nodes.size() == (size_t)fr.n_slots * spira::kBvhNodeDwords && fr.n_slots >= 1 && fr.depth < spira::kBvhStack - 2);
     std::vector<char> seen(n, 0);                       // every triangle exactly once
     for (uint32_t i = 0; i < n; ++i) { uint32_t oi = bits_of(tris[3 * (size_t)i].w); CHECK(oi < n && !seen[oi]); if (oi < n) seen[oi] = 1; }
     std::mt19937 rng(seed);
     std::uniform_real_distribution<double> U(-1, 1);
     uint32_t hits = 0;
+    Stats8 st;
     for (uint32_t r = 0; r < n_rays; ++r) {
         const uint32_t k = rng() % n;                   // aim at a random triangle's first vertex (+ noise) from a random origin
-        V<T> o = {(T)(4 * U(rng)), (T)(4 * U(rng)), (T)(4 * U(rng))};
+        const double far = (r % 7 == 3) ? 40.0 : 4.0;   // some origins far outside the mesh, some (below) on a triangle of it
+        V<T> o = {(T)(far * U(rng)), (T)(far * U(rng)), (T)(far * U(rng))};
+        if (r % 5 == 1) { const uint32_t k2 = rng() % n; o = {t10[10 * (size_t)k2 + 3], t10[10 * (size_t)k2 + 4], t10[10 * (size_t)k2 + 5]}; }
         V<T> tgt = {t10[10 * (size_t)k] + (T)(0.3 * U(rng)), t10[10 * (size_t)k + 1] + (T)(0.3 * U(rng)), t10[10 * (size_t)k + 2] + (T)(0.3 * U(rng))};
         V<T> d = sub(tgt, o);
+        if (r % 11 == 5) d.x = 0;                       // axis-parallel rays: the clamped reciprocal
+        if (r % 13 == 6) { d.y = 0; d.z = 0; }
         T len = std::sqrt(dot(d, d));
         if (!(len > 0)) continue;
         d = {d.x / len, d.y / len, d.z / len};
@@ -122,11 +159,12 @@ static void check_mesh(const char *name, const std::vector<T> &t10, uint32_t n_r
             if (tri_test<T>(v0, e1, e2, o, d, (T)0.001, c_lin, tt)) { c_lin = tt; p_lin = (int)i; }
         }
         T c_bvh = INFINITY; int p_bvh = -1;
-        traverse<T>(nodes, tris, o, d, (T)0.001, c_bvh, p_bvh);
+        traverse<T>(nodes, tris, fr, o, d, (T)0.001, c_bvh, p_bvh, st);
         CHECK(p_lin == p_bvh && (p_lin < 0 || std::memcmp(&c_lin, &c_bvh, sizeof(T)) == 0));
         hits += p_lin >= 0;
     }
-    std::printf("%-28s n=%-7u nodes=%-7zu depth=%-3d rays=%u hits=%u\n", name, n, nodes.size() / 4, depth, n_rays, hits);
+    std::printf("%-28s n=%-7u slots=%-7u depth=%-3d rays=%u hits=%u  nodes/ray=%.1f tris/ray=%.1f stack=%d\n", name, n, fr.n_slots, fr.depth, n_rays, hits,
+                (double)st.nodes / n_rays, (double)st.tris / n_rays, st.max_sp);
 }
 
 template <class T> static std::vector<T> soup(uint32_t n, uint32_t seed, double size) {
@@ -215,9 +253,11 @@ static void validation_checks() {
     t10[4] = NAN; CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == SPIRA_E_INVALID);
     t10[4] = 0; t10[9] = 0; CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == SPIRA_E_INVALID);
     CHECK(spira::scene_arrays_check<double>(nullptr, nullptr, nullptr, 0, 1, 0, &msg) == SPIRA_E_INVALID);
-    std::vector<spira::HostPack4<float>> nodes, tris;
-    CHECK(!spira::bvh_build<float>(nullptr, 0, nodes, tris, nullptr));                            // empty
-    CHECK(!spira::bvh_build<float>(nullptr, (1u << 24) + 1, nodes, tris, nullptr));               // over the 2^24 limit: rejected before any read
+    std::vector<uint32_t> nodes;
+    std::vector<spira::HostPack4<float>> tris;
+    spira::BvhFrame<float> fr{};
+    CHECK(!spira::bvh_build<float>(nullptr, 0, nodes, tris, fr));                                 // empty
+    CHECK(!spira::bvh_build<float>(nullptr, (1u << 24) + 1, nodes, tris, fr));                    // over the 2^24 limit: rejected before any read
 }
 
 static void oracle_checks() {   // the checker itself under ASan/UBSan: S2-like scene, all estimators, extensions, tilings, row orders
