@@ -36,7 +36,7 @@ SCENE_DESC = {"s1": "create_scene() of src/spira-metal-optimized.jl", "s2": "cre
               "s3": "S1 inside a closed box", "s4": "create_scene_with_obj() of examples/julia-raytracer.jl with an 81 920-triangle procedural mesh (BVH)"}
 CONFIGS = {   # BASELINE.json configs[2..4]: scene, spp, depth, spp is per GPU (weak) or in total (strong)
     "c3": dict(scene="s1", spp=64, depth=8, scaling="weak", name="BASELINE configs[2]"),
-    "c4": dict(scene="s1", spp=256, depth=8, scaling="strong", name="BASELINE configs[3]"),
+    "c4": dict(scene="s3", spp=256, depth=8, scaling="strong", name="BASELINE configs[3]"),      # BASELINE.md §3 / SURVEY §8d: c4 runs on S3
     "c5": dict(scene="s4", spp=64, depth=12, scaling="weak", name="BASELINE configs[4]"),
 }
 
@@ -47,6 +47,24 @@ def algorithmic_bytes(c, prec_bytes, kernel):
     already holds radiance.  Packet: 10 values (+ a 4-byte hit reference in the Float32 hit queues of k_path)."""
     packet = 10 * prec_bytes + (4 if (kernel == "wavefront" and prec_bytes == 4) else 0)
     return 2 * packet * c["rays_enqueued"] + (3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes
+
+
+KERNEL_SOURCES = ("spira_device.h", "spira_hip.hip", "spira_bvh.h")
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the kernel sources: profiles/traffic_*.json carry the hash of the sources they were measured on
+    (profiles/summarize.py), and PMC figures of other sources are never attached to a bench line."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "julia-spira_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def metric_string(W, H, spp, depth):
+    return "Msamples/sec at %dx%d spp=%d depth=%d; fraction of HBM roofline" % (W, H, spp, depth)
 
 
 def host_cpu_share():
@@ -64,15 +82,17 @@ def host_cpu_share():
     return n
 
 
-def roofline_record(c, prec, kernel, scene, is_headline_shape):
-    """Roofline of the dominant kernel from one render's counters (spira_get_counters)."""
+def roofline_record(c, prec, kernel, scene, is_headline_shape, source_hash=None):
+    """Roofline of the dominant kernel from one render's counters (spira_get_counters).  `is_headline_shape`: the run has the launch
+    shape the committed PMC summaries were taken on (1080p, 64 sample slots per pass, one GPU) — only then are they attached, and
+    only when they were measured on the kernel sources of this run (`source_hash`; None = the sources as they are on disk)."""
     pb = 4 if prec == "f32" else 8
     nbytes = algorithmic_bytes(c, pb, kernel)
     launches = max(1, c["bounce_launches"])
     kms = c["bounce_kernel_ms"]
     achieved = nbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     rec = {"bound": "hbm", "kernel": "k_path" if kernel == "wavefront" else "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "traffic_source": None, "traffic_stale": False,
            "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(kms / launches, 5), "launches": launches,
            "kernel_ms_per_step": round(kms, 4), "bytes_per_sample": round(nbytes / c["samples"], 2),
            "segments_per_sample": round(c["segments"] / c["samples"], 4), "packets_per_sample": round(c["rays_enqueued"] / c["samples"], 4),
@@ -83,18 +103,26 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape):
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
     if is_headline_shape and os.path.exists(tfile):      # PMC figures of this same command (profiles/run_profile.sh)
         tj = json.load(open(tfile))
-        if tj.get("kernel") == rec["kernel"]:
+        if source_hash is None:
+            source_hash = kernel_source_hash()
+        if tj.get("kernel") != rec["kernel"]:
+            pass
+        elif tj.get("source_hash") != source_hash:
+            # measured on other kernel sources: nothing of it reaches the line, and no bound is claimed beyond what this run measured itself
+            rec["traffic_stale"], rec["bound"] = True, None
+            rec["traffic_source"] = "profiles/%s (stale: taken on sources %s, this run is %s)" % (os.path.basename(tfile), tj.get("source_hash"), source_hash)
+        else:
             rec["traffic"], rec["traffic_source"] = round(tj["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(tfile)
-            if tj.get("valu") and tj["valu"].get("issue_frac"):
-                v = tj["valu"]
-                rec["valu"] = {"issue_frac": v["issue_frac"], "simd_cycles_per_valu_inst": v["simd_cycles_per_valu_inst"],
-                               "modelled_cycles_per_valu_inst": v["modelled_cycles_per_valu_inst"], "lane_utilisation": v["lane_utilisation"],
-                               "wave_cycle_shares": v.get("wave_cycle_shares"),
-                               "what": "VALU-issue roofline of this kernel: PMC instruction counts per class x the SIMD cycles one wave64 instruction "
-                                       "of that class holds the issue port (profiles/microbench/valu_peak.hip), over the SIMD cycles of the "
-                                       "dispatches (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); rocprofv3 --pmc passes of this same command",
+            v = tj.get("valu")
+            if v and v.get("busy_frac"):
+                rec["valu"] = {"busy_frac": v["busy_frac"], "lane_utilisation": v["lane_utilisation"], "simd_cycles_per_valu_inst": v["simd_cycles_per_valu_inst"],
+                               "wave_cycle_shares": v.get("wave_cycle_shares"), "priced_model": v.get("priced_model"),
+                               "what": "measured by PMC on this same command (rocprofv3 --pmc passes, profiles/run_profile.sh): busy_frac = 4 x SQ_ACTIVE_INST_VALU "
+                                       "(quad-cycles) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = the share of SIMD cycles in which a VALU instruction executes; "
+                                       "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); priced_model (secondary) = instruction counts per "
+                                       "class x the issue cost of each class (profiles/microbench/valu_peak.hip), with the share of instructions no class counter covers",
                                "source": rec["traffic_source"]}
-                if v["issue_frac"] > rec["frac"]:
+                if v["busy_frac"] > rec["frac"]:
                     rec["bound"] = "valu"
     return rec
 
@@ -155,7 +183,9 @@ def main():
     tile = D.tile_params(H, world, rank)
     rows = tile["rows"] or H
     stream = torch.cuda.current_stream()
-    headline_shape = (W, H, spp_total, depth, world) == (1920, 1080, 64, 8, 1)
+    # the committed PMC summaries were taken at 1080p with 64 sample slots per pass on one GPU: any spp that is a multiple of 64 launches the same shape
+    pmc_shape = (W, H, world) == (1920, 1080, 1) and spp_total % 64 == 0 and depth == cfg["depth"]
+    src_hash = kernel_source_hash()
 
     def workload(name):
         s = builders[name]()
@@ -201,11 +231,13 @@ def main():
     samples_per_step = W * H * spp_total
     value = samples_per_step * args.steps / dt / 1e6
 
-    def side_run(scene, kernel, prec, reps=5, sem=0):
+    def side_run(scene, kernel, prec, reps=5, sem=0, spp=None, dep=None, seed_=None):
         """An extra, untimed-region measurement on rank 0: (Msamples/s, ms per step, roofline record)."""
         sc2, counts2 = workload(scene)
         fl = kflags[kernel] | B.POST_NONE | sem
-        pp = B.make_params(W, H, spp_total, depth, *counts2, flags=fl, seed=seed, **tile)
+        spp_ = spp_total if spp is None else spp
+        dep_ = depth if dep is None else dep
+        pp = B.make_params(W, H, spp_, dep_, *counts2, flags=fl, seed=seed if seed_ is None else seed_, **tile)
         o2 = torch.empty((3, rows, W), dtype=tdt[prec], device="cuda")
         with B.Scene(sc2[0], sc2[1], sc2[2], prec) as h2:
             for _ in range(3):                 # warm-up: a configuration's first launches run slower (profiles/r02_*.md)
@@ -231,21 +263,21 @@ def main():
         elif sem:
             roof = {"segments_per_sample": round(c["segments"] / c["samples"], 4)}
         elif kernel == "wavefront":
-            roof = roofline_record(c, prec, kernel, scene, headline_shape)
+            roof = roofline_record(c, prec, kernel, scene, (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12}.get(scene, 8), src_hash)
         elif kernel == "bounce":     # per-bounce launches are only bracketed on request (it slows the render): one extra, profiled render
-            B.render_device(*sc2, B.make_params(W, H, spp_total, depth, *counts2, flags=fl | B.FLAG_PROFILE, seed=seed, **tile),
+            B.render_device(*sc2, B.make_params(W, H, spp_, dep_, *counts2, flags=fl | B.FLAG_PROFILE, seed=seed, **tile),
                             o2.data_ptr(), 0, stream.cuda_stream, prec)
             torch.cuda.synchronize()
-            roof = roofline_record(B.counters(), prec, kernel, scene, headline_shape)
+            roof = roofline_record(B.counters(), prec, kernel, scene, (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12}.get(scene, 8), src_hash)
             roof["note"] = "kernel time from a separate event-bracketed render (slower than the timed steps)"
         del o2
-        return samples_per_step / adt / 1e6, adt * 1e3, roof
+        return W * H * spp_ / adt / 1e6, adt * 1e3, roof
 
     result = None
     if rank == 0:
         assert bool(torch.isfinite(img).all()), "non-finite pixels"
         if args.kernel == "wavefront":
-            roof = roofline_record(c_timed, args.prec, args.kernel, scene_name, headline_shape)
+            roof = roofline_record(c_timed, args.prec, args.kernel, scene_name, pmc_shape, src_hash)
         elif args.kernel == "bounce":
             roof = side_run(scene_name, "bounce", args.prec, reps=1)[2]
         else:
@@ -275,6 +307,32 @@ def main():
                 for name, sem, k in (("metal_wavefront", B.SEM_METAL, "wavefront"), ("metal_one_lane_per_pixel", B.SEM_METAL, "mega"), ("cpu_one_lane_per_path", B.SEM_CPU, "mega")):
                     v, ms, eroof = side_run(scene_name, k, args.prec, sem=sem)
                     estimators[name] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "dtype": args.prec, "roofline": eroof}
+        # ---- the other BASELINE configurations that fit one GPU (N=1 only): configs[3] = 1080p spp 256 depth 8 on S3 (4 passes of 64 sample slots; on
+        # 8 GPUs every rank renders its 135-row share of this), configs[4] = the 81 920-triangle mesh scene S4 at depth 12 — both precisions each
+        other_configs = None
+        if world == 1 and not args.no_extras and (W, H) == (1920, 1080):
+            other_configs = {}
+            for cname in ("c4", "c5"):
+                if cname == args.config:
+                    continue
+                cc = CONFIGS[cname]
+                entry = {"workload": "%s: %dx%d spp=%d depth=%d, scene %s (%s)" % (cc["name"], W, H, cc["spp"], cc["depth"], cc["scene"], SCENE_DESC[cc["scene"]]),
+                         "metric": metric_string(W, H, cc["spp"], cc["depth"])}
+                for pr in ("f64", "f32"):
+                    v, ms, croof = side_run(cc["scene"], "wavefront", pr, reps=3, spp=cc["spp"], dep=cc["depth"], seed_=scenes.seed_for({"c4": 4, "c5": 5}[cname]))
+                    entry[pr] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": croof}
+                other_configs[cname] = entry
+        # ---- end to end through the host-buffer entry point (N=1 only; never `value`): scene arrays in, image out to host memory — validation,
+        # upload, the same kernels, one device-to-host copy of the frame (SURVEY §8d asks for it beside the device-resident figure)
+        end_to_end = None
+        if world == 1 and not args.no_extras:
+            hdr_host, _ = B.render(sc[0], sc[1], sc[2], sc[3], params, args.prec)      # warm-up (pageable host memory, like a caller's)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                hdr_host, _ = B.render(sc[0], sc[1], sc[2], sc[3], params, args.prec)
+            e2e = (time.perf_counter() - t1) / 3
+            end_to_end = {"ms": round(e2e * 1e3, 3), "value": round(samples_per_step / e2e / 1e6, 3), "unit": "Msamples/s", "d2h_bytes": int(hdr_host.nbytes),
+                          "what": "spira_render_%s with host pointers: scene validation + upload, kernels, one D2H copy of the planar frame into pageable memory, synchronous" % args.prec}
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -303,7 +361,7 @@ def main():
                 cpu["single_thread_value"] = round(W * 64 * 16 / sdt / 1e6, 4)
                 cpu["single_thread_sample"] = "rows %d..%d of the same frame at spp=16, 1 thread, %.1f s" % (H // 2 - 32, H // 2 + 31, sdt)
         result = {
-            "metric": "Msamples/sec at 1920x1080 spp=64 depth=8; fraction of HBM roofline",
+            "metric": metric_string(W, H, spp_total, depth),
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": args.prec, "data": "synthetic",
@@ -313,7 +371,8 @@ def main():
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": scene_name, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
-            "roofline": roof, "cpu_baseline": cpu, "other_precision": alt, "stress": stress, "organisations": orgs, "estimators": estimators,
+            "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "configs": other_configs, "other_precision": alt, "stress": stress,
+            "organisations": orgs, "estimators": estimators, "kernel_source_hash": src_hash,
         }
         print(json.dumps(result), flush=True)
     scene_h.destroy()

@@ -251,8 +251,12 @@ template <class T> struct SceneGlobal {     // flat arrays exactly as passed thr
     const T *spd;           // device copy of the SPD table, or NULL (extension off)
 };
 
-__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // box tests only (conservative)
-__device__ __forceinline__ double rcp_fast(double x) { return 1.0 / x; }
+// box tests only (conservative: the boxes are padded by 1e-4 of the mesh's extent, these reciprocals are good to 1e-7 / 1e-15)
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rcp_fast(double x) {       // v_rcp_f64 + one Newton step (3 instructions; the IEEE division is ~30).  x = 0: NaN, which
+    const double r = __builtin_amdgcn_rcp(x);                 // the NaN-ignoring min / max of box_entry() read as "no constraint from this axis"
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
 __device__ __forceinline__ float min_nn(float a, float b) { return __builtin_fminf(a, b); }  // NaN-ignoring
 __device__ __forceinline__ float max_nn(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double min_nn(double a, double b) { return __builtin_fmin(a, b); }

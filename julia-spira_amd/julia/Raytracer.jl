@@ -1,7 +1,9 @@
 # Raytracer.jl — the surface of the reference's oracle script (examples/julia-raytracer.jl) over the MI355X backend:
 #   Vec3 / Ray / Material(; diffuse, emission, specular, roughness) / Sphere / Triangle / Mesh / HittableList / BoundingVolumeHierarchy /
 #   Camera(; position, look_at, up, fov, aspect_ratio, aperture, focus_dist) / render(world, camera, W, H; samples_per_pixel, max_depth)
-#   -> (img::Matrix{RGB{Float32}}, hdr_data::Matrix{Vec3}) / to_acescg / save_exr
+#   -> (img::Matrix{RGB{Float32}}, hdr_data::Matrix{Vec3}) / to_acescg / save_exr /
+#   load_obj_mesh(filename, material; scale, rotation, translation, center, normalize_size) / create_scene() / create_scene_with_obj() /
+#   render_example(; width, height, samples, interactive, output_file, scene, camera)  — what tests/bunny-test.jl:37-60 calls
 # in Float64, the script's precision (spira_render_f64, SPIRA_SEM_A: the estimator this build is graded on), triangles included
 # (more than 32 of them go through the device BVH; the result is the script's linear closest-hit scan, :213-258).
 # Dependencies: Colors only (already a dependency of the reference, Project.toml:8).
@@ -13,7 +15,7 @@ module Raytracer
 using Colors
 
 export Vec3, Ray, Material, Sphere, Triangle, Mesh, Hittable, HittableList, BoundingVolumeHierarchy, Camera,
-       render, to_acescg, save_exr, flatten_world
+       render, to_acescg, save_exr, flatten_world, load_obj_mesh, create_scene, create_scene_with_obj, render_example
 
 const libspira = get(ENV, "SPIRA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libspira_hip.so"))
 
@@ -83,6 +85,12 @@ const SPIRA_POST_ACES = 0x00000000     # to_acescg :370-384: clamp(aces(x), 0, 1
 
 spira_error(rc) = error("libspira_hip error $rc: " * unsafe_string(ccall((:spira_last_error, libspira), Cstring, ())))
 
+const SPIRA_ABI_VERSION = 2            # of the include/spira_hip.h these ccalls and SpiraParams were written against
+function __init__()                    # a stale library (SPIRA_HIP_LIB, an old build) would read SpiraParams with another layout
+    have = ccall((:spira_abi_version, libspira), Cint, ())
+    have == SPIRA_ABI_VERSION || error("$libspira has ABI version $have, this module was written for $SPIRA_ABI_VERSION")
+end
+
 struct Camera                          # :261-295 (the arithmetic runs in spira_camera_lookat_f64; lens ignored like get_ray :299-300)
     position::Vec3
     lower_left_corner::Vec3
@@ -105,9 +113,12 @@ end
 function flatten_world(world::Hittable)
     spheres = Float64[]; tris = Float64[]; mats = Float64[]
     seen_triangle = false
-    function material_index(m::Material)
-        append!(mats, [m.diffuse.x, m.diffuse.y, m.diffuse.z, m.emission.x, m.emission.y, m.emission.z, m.specular, m.roughness])
-        return length(mats) ÷ 8
+    mat_index = Dict{Material,Int}()       # Material is an immutable struct of bits: one table row per distinct VALUE — a mesh of 81 920
+    function material_index(m::Material)   # triangles shares one material (:598) and must not need 81 920 rows of LDS (spira_hip/raytracer.py: one per object)
+        get!(mat_index, m) do
+            append!(mats, [m.diffuse.x, m.diffuse.y, m.diffuse.z, m.emission.x, m.emission.y, m.emission.z, m.specular, m.roughness])
+            length(mats) ÷ 8
+        end
     end
     function visit(obj::Hittable)
         if obj isa HittableList || obj isa BoundingVolumeHierarchy
@@ -153,6 +164,104 @@ function render(world::Hittable, camera::Camera, width::Int, height::Int; sample
         hdr_data[j, i] = Vec3(hdr[i, j, 1], hdr[i, j, 2], hdr[i, j, 3])
     end
     return out_img, hdr_data
+end
+
+# load_obj_mesh(filename, material; scale, rotation, translation, center, normalize_size) (:466-602) -> Vector{Hittable} of Triangles.
+# `v` and `f` records only, first index of `a/b/c`, n-gons as fans (:498-505); then the reference's vertex pipeline in its order:
+# bounding-box centre -> normalise by the largest box dimension -> rotate about X, Y, Z (degrees) -> scale -> translate (:510-591).
+function load_obj_mesh(filename::String, material::Material; scale::Vec3=Vec3(1.0, 1.0, 1.0), rotation::Vec3=Vec3(0.0, 0.0, 0.0),
+                       translation::Vec3=Vec3(0.0, 0.0, 0.0), center::Bool=true, normalize_size::Bool=false)
+    vertices = Vec3[]; faces = NTuple{3,Int}[]
+    for line in eachline(filename)
+        if startswith(line, "v ")
+            p = split(line)
+            push!(vertices, Vec3(parse(Float64, p[2]), parse(Float64, p[3]), parse(Float64, p[4])))
+        elseif startswith(line, "f ")
+            idx = [parse(Int, split(tok, "/")[1]) for tok in split(line)[2:end]]
+            for i in 3:length(idx)                                   # a triangle is a fan of one
+                push!(faces, (idx[1], idx[i-1], idx[i]))
+            end
+        end
+    end
+    if (center || normalize_size) && !isempty(vertices)              # :511
+        lo = Vec3(minimum(v.x for v in vertices), minimum(v.y for v in vertices), minimum(v.z for v in vertices))
+        hi = Vec3(maximum(v.x for v in vertices), maximum(v.y for v in vertices), maximum(v.z for v in vertices))
+        center_point = (lo + hi) / 2.0                               # :521
+        max_dimension = max(hi.x - lo.x, max(hi.y - lo.y, hi.z - lo.z))
+        center && (vertices = [v - center_point for v in vertices])                              # :526-530
+        (normalize_size && max_dimension > 0) && (vertices = [v * (1.0 / max_dimension) for v in vertices])   # :533-538
+    end
+    if rotation.x != 0 || rotation.y != 0 || rotation.z != 0         # :543
+        vertices = map(vertices) do v
+            if rotation.x != 0
+                th = deg2rad(rotation.x); v = Vec3(v.x, v.y * cos(th) - v.z * sin(th), v.y * sin(th) + v.z * cos(th))
+            end
+            if rotation.y != 0
+                th = deg2rad(rotation.y); v = Vec3(v.x * cos(th) + v.z * sin(th), v.y, -v.x * sin(th) + v.z * cos(th))
+            end
+            if rotation.z != 0
+                th = deg2rad(rotation.z); v = Vec3(v.x * cos(th) - v.y * sin(th), v.x * sin(th) + v.y * cos(th), v.z)
+            end
+            v
+        end
+    end
+    if scale.x != 1.0 || scale.y != 1.0 || scale.z != 1.0           # :576
+        vertices = [Vec3(v.x * scale.x, v.y * scale.y, v.z * scale.z) for v in vertices]
+    end
+    if translation.x != 0.0 || translation.y != 0.0 || translation.z != 0.0      # :587
+        vertices = [v + translation for v in vertices]
+    end
+    return Hittable[Triangle([vertices[a], vertices[b], vertices[c]], material) for (a, b, c) in faces]      # 1-based OBJ indices, :594-599
+end
+
+# the camera both example scenes use (:632-638, :697-703)
+example_camera() = Camera(position=Vec3(0.0, 1.0, 3.0), look_at=Vec3(0.0, 0.0, -1.0), up=Vec3(0.0, 1.0, 0.0), fov=45.0, aspect_ratio=16.0 / 9.0)
+
+# create_scene() (:605-641) -> (scene, camera): five spheres and a triangle
+function create_scene()
+    objects = Hittable[
+        Sphere(Vec3(0, -100.5, -1), 100, Material(diffuse=Vec3(0.8, 0.8, 0.2))),
+        Sphere(Vec3(0, 0, -1), 0.5, Material(diffuse=Vec3(0.8, 0.2, 0.2))),
+        Sphere(Vec3(1, 0, -1), 0.5, Material(diffuse=Vec3(0.8, 0.6, 0.2), specular=0.8, roughness=0.3)),
+        Sphere(Vec3(-1, 0, -1), 0.5, Material(diffuse=Vec3(0.8, 0.8, 0.8), specular=1.0, roughness=0.0)),
+        Sphere(Vec3(0, 2, 0), 0.5, Material(diffuse=Vec3(0.8, 0.8, 0.8), emission=Vec3(4, 4, 4))),
+        Triangle([Vec3(-0.5, 0, -2), Vec3(0.5, 0, -2), Vec3(0, 1, -2)], Material(diffuse=Vec3(0.2, 0.8, 0.2)))]
+    return BoundingVolumeHierarchy(objects), example_camera()
+end
+
+# create_scene_with_obj() (:644-706) -> (scene, camera): ground, light and the OBJ mesh — or a sphere when the file is missing (:687-691).
+# `obj_file` is an addition (the reference hard-codes ~/Downloads/bunny.obj).
+function create_scene_with_obj(obj_file::String=expanduser("~/Downloads/bunny.obj"))
+    objects = Hittable[Sphere(Vec3(0, -100.5, -1), 100, Material(diffuse=Vec3(0.8, 0.8, 0.2))),
+                       Sphere(Vec3(0, 2, 0), 0.5, Material(diffuse=Vec3(0.8, 0.8, 0.8), emission=Vec3(4, 4, 4)))]
+    mesh_material = Material(diffuse=Vec3(0.7, 0.3, 0.2), specular=0.2, roughness=0.4)
+    if isfile(obj_file)
+        println("Loading OBJ mesh from: $obj_file")
+        mesh_triangles = load_obj_mesh(obj_file, mesh_material, center=true, normalize_size=true, scale=Vec3(0.5, 0.5, 0.5),
+                                       rotation=Vec3(0.0, 90.0, 0.0), translation=Vec3(0.0, 0.0, -1.0))
+        append!(objects, mesh_triangles)
+        println("Added $(length(mesh_triangles)) triangles to the scene")
+    else
+        println("OBJ file not found, adding a sphere instead")
+        push!(objects, Sphere(Vec3(0, 0, -1), 0.5, mesh_material))
+    end
+    return BoundingVolumeHierarchy(objects), example_camera()
+end
+
+# render_example(; width, height, samples, interactive, output_file, scene, camera) (:709-732) -> (image, hdr_data).
+# `interactive` is accepted and ignored: this module has no plotting dependency (the reference displays through Plots, :727).
+function render_example(; width=1280, height=720, samples=200, interactive=true, output_file="render.exr", scene=nothing, camera=nothing)
+    if scene === nothing || camera === nothing
+        println("No scene provided, creating default scene...")
+        scene, camera = create_scene()
+    end
+    println("Rendering with $samples samples per pixel...")
+    image, hdr_data = render(scene, camera, width, height, samples_per_pixel=samples, max_depth=25)
+    if output_file != ""
+        println("Saving to $output_file...")
+        save_exr(hdr_data, output_file)
+    end
+    return image, hdr_data
 end
 
 # save_exr(hdr_data, filename) (:424-463): scanline, uncompressed, 32-bit FLOAT R/G/B; no Images / FileIO needed.

@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("SPIRA_HIP_LIB", os.path.join(CSRC, "libspira_hip.so"))   # same override as julia/SPIRA.jl
 
+ABI_VERSION = 2      # SPIRA_ABI_VERSION of the include/spira_hip.h this binding was written against (struct layouts, flag values)
+
 # ---- flags (include/spira_hip.h) ----
 SEM_A, SEM_CPU, SEM_METAL = 0x0, 0x1, 0x2
 KERNEL_DEFAULT, KERNEL_MEGA, KERNEL_BOUNCE, KERNEL_WAVEFRONT = 0x00, 0x10, 0x20, 0x30
@@ -78,6 +80,10 @@ def lib():
         _lib.spira_stripe_rows.argtypes = [C.c_uint32] * 4
         for name in EXPORTS:
             getattr(_lib, name)  # AttributeError if an ABI symbol is missing
+        have = _lib.spira_abi_version()
+        if have != ABI_VERSION:      # a stale library (SPIRA_HIP_LIB, an old build directory): other struct sizes and flag values
+            _lib = None
+            raise SpiraError("%s has ABI version %d, this binding was written for %d" % (LIB_PATH, have, ABI_VERSION))
     return _lib
 
 

@@ -11,6 +11,8 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 
 # SIMD cycles (at a nominal 2.4 GHz, i.e. a time) one wave64 VALU instruction of a class holds the issue port, measured on MI355X with
 # profiles/microbench/valu_peak.hip (inline-assembly streams of independent instructions, 4 waves per SIMD; profiles/r02_valu_peak.txt).  "other" = what the class
@@ -41,7 +43,7 @@ def main():
     st = os.path.join(src, "trace", "trace_kernel_stats.csv")
     if os.path.exists(st):
         lines += ["## --kernel-trace --stats", "", "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---:|---:|---:|---:|---:|---:|"]
-        tot_b = cnt_b = 0
+        tot_b = cnt_b = spec_calls = 0
         path_calls = []
         for r in csv.DictReader(open(st)):
             if float(r["Percentage"]) < 0.05:
@@ -53,10 +55,13 @@ def main():
                 cnt_b += int(r["Calls"])
                 if "k_path" in r["Name"]:
                     path_calls.append(int(r["Calls"]))
+                    if short(r["Name"]).endswith(", true>"):
+                        spec_calls += int(r["Calls"])
         if path_calls:
-            # one k_path "launch" is the speculative-division instantiation <..., true> plus the exact one <..., false> behind it, which
-            # renders again the waves the first reported (normally none: its workgroups return at once); HIP events in bench.py bracket both
-            cnt_b = max(path_calls)
+            # one k_path "launch" (= one pass) is the speculative-division instantiation <..., true>, the exact one <..., false> behind it, which
+            # renders again the waves the first reported (normally none: its workgroups return at once) and, on mesh scenes, the exact
+            # instantiation once more for the fat waves that walk the tree; HIP events in bench.py bracket all of them
+            cnt_b = spec_calls if spec_calls else max(path_calls)
         if cnt_b:
             lines += ["", "dominant kernel (k_path: speculative launch + its exact follow-up counted as one; k_bounce: all instantiations): %d launches, average %.2f us" %
                       (cnt_b, tot_b / cnt_b / 1e3), ""]
@@ -64,15 +69,15 @@ def main():
     if os.path.exists(kt):       # launch by launch: the first launches of a process are slower than the steady state bench.py times
         d = []
         rows = sorted((r for r in csv.DictReader(open(kt)) if "k_path" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
-        prev_spec = False
+        had_spec = False
         for r in rows:
             us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             spec = short(r["Kernel_Name"]).endswith(", true>")
-            if prev_spec and not spec:
-                d[-1] += us                   # the exact follow-up of the speculative launch just before it
+            if d and not spec and had_spec:
+                d[-1] += us                   # the exact launches behind a speculative one belong to its pass (follow-up; mesh scenes: the fat waves)
             else:
                 d.append(us)
-            prev_spec = spec
+            had_spec = had_spec or spec
         if len(d) >= 4:
             half = d[len(d) // 2:]
             lines += ["k_path launch by launch (us): " + ", ".join("%.0f" % x for x in d),
@@ -137,14 +142,17 @@ def main():
         ks = [k for k in agg if k.startswith(dom)]
         # launches: k_bounce instantiations are launches of their own; the k_path instantiations of one run are the speculative launch and
         # its exact follow-up, together one launch
-        launches_of = (lambda name: max([calls[k].get(name, 0) for k in ks] or [0])) if dom == "k_path" else (lambda name: sum(calls[k].get(name, 0) for k in ks))
+        spec_ks = [k for k in ks if k.endswith(", true>")]
+        launches_of = ((lambda name: sum(calls[k].get(name, 0) for k in spec_ks) if spec_ks else max([calls[k].get(name, 0) for k in ks] or [0]))
+                       if dom == "k_path" else (lambda name: sum(calls[k].get(name, 0) for k in ks)))
         nl = launches_of("FETCH_SIZE")
         if not nl:
             continue
         import json
         tot = lambda name: sum(agg[k].get(name, 0) for k in ks)
         rd, wr = tot("FETCH_SIZE") * 1024, tot("WRITE_SIZE") * 1024
-        out = {"kernel": dom, "launches": nl, "fetch_bytes_raw": rd, "fetch_bytes_x2": 2 * rd, "write_bytes": wr,
+        import bench
+        out = {"kernel": dom, "launches": nl, "source_hash": bench.kernel_source_hash(), "fetch_bytes_raw": rd, "fetch_bytes_x2": 2 * rd, "write_bytes": wr,
                "hbm_bytes_per_launch": (2 * rd + wr) / nl,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB units); FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md HBM section (gfx950 reports half of a 16 B/lane streaming read)",
@@ -170,19 +178,23 @@ def main():
                     mix[cname.replace("SQ_INSTS_VALU_", "").lower()] = round(cnt / n_inst, 4)
                     covered += cnt
                     weighted += cnt * cost * MICROBENCH_CLOCK_GHZ / 2.4
-            issue_frac = None
+            priced = None
             if mix:
                 other = VALU_COST["other_f64"] if mix.get("fma_f64", 0) > mix.get("fma_f32", 0) else VALU_COST["other_f32"]
                 weighted += max(0.0, n_inst - covered) * other * MICROBENCH_CLOCK_GHZ / 2.4
                 mix["other"] = round(max(0.0, n_inst - covered) / n_inst, 4)
-                issue_frac = round(weighted / simd_cycles, 4)
-            out["valu"] = {"issue_frac": issue_frac, "simd_cycles_per_valu_inst": round(simd_cycles / n_inst, 3), "effective_clock_GHz": round(tot("GRBM_GUI_ACTIVE") / 8 / max(wall_ns, 1.0), 3),
-                           "modelled_cycles_per_valu_inst": round(weighted / n_inst, 3) if mix else None, "mix": mix or None,
-                           "issue_cost_table": VALU_COST if mix else None,
+                priced = {"frac": round(weighted / simd_cycles, 4), "modelled_cycles_per_valu_inst": round(weighted / n_inst, 3), "mix": mix,
+                          "other_share": mix["other"], "issue_cost_table": VALU_COST,
+                          "note": "a model, not a measurement: the share of instructions no class counter covers is priced with one average (+-8 %)"}
+            # MEASURED: SQ_ACTIVE_INST_VALU counts quad-cycles in which a VALU instruction executes, summed over the SIMDs
+            busy = 4.0 * tot("SQ_ACTIVE_INST_VALU") / simd_cycles
+            out["valu"] = {"busy_frac": round(busy, 4), "simd_cycles_per_valu_inst": round(simd_cycles / n_inst, 3),
+                           "effective_clock_GHz": round(tot("GRBM_GUI_ACTIVE") / 8 / max(wall_ns, 1.0), 3),
                            "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / max(1.0, 64 * tot("SQ_ACTIVE_INST_VALU")), 4),
                            "valu_insts_per_launch": tot("SQ_INSTS_VALU") / max(1, launches_of("SQ_INSTS_VALU")),
                            "wave_cycle_shares": {"wait_any": round(tot("SQ_WAIT_ANY") / w, 3), "wait_inst_any": round(tot("SQ_WAIT_INST_ANY") / w, 3),
-                                                 "active_inst_any": round(tot("SQ_ACTIVE_INST_ANY") / w, 3)} if w else None}
+                                                 "active_inst_any": round(tot("SQ_ACTIVE_INST_ANY") / w, 3)} if w else None,
+                           "priced_model": priced}
         json.dump(out, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
         break
     open(dst, "w").write("\n".join(lines) + "\n")

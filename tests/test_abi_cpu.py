@@ -242,6 +242,63 @@ def test_julia_ccalls_match_header_argument_by_argument():
         assert m and int(m.group(1), 16) == int(val, 16), const
 
 
+def _julia_exports(fname):
+    src = open(os.path.join(ROOT, "julia-spira_amd", "julia", fname)).read()
+    m = re.search(r"^export (.*?)\n\n", src, flags=re.S | re.M)
+    return set(x.strip() for x in m.group(1).replace("\n", " ").split(",") if x.strip()), src
+
+
+def test_julia_export_lists_cover_the_reference_and_the_python_twins():
+    """Each Julia module exports what the reference surface it stands in for exports / defines, and what its executable Python twin
+    offers (a maintainer swapping the module into tests/bunny-test.jl must not meet an UndefVarError)."""
+    ex, src = _julia_exports("SPIRA.jl")
+    # /root/reference/src/SPIRA.jl:11-13
+    assert {"Scene", "Camera", "Material", "Sphere", "Ray", "render", "create_scene", "render_hybrid_gpu", "render_with_cpu"} <= ex
+    from spira_hip import spira
+    twin = {n for n in ("Scene", "Camera", "Material", "Sphere", "Ray", "render", "create_scene", "prepare_scene_data", "render_hybrid_gpu", "render_with_cpu")
+            if hasattr(spira, n)}
+    assert twin <= ex, twin - ex
+    for kw in ("semantics::Symbol=:A", "flags=nothing"):      # the estimator can be chosen from Julia too (spira.py: semantics=)
+        assert kw in src[src.index("function render(scene::Scene"):], kw
+    assert set(re.findall(r":(A|cpu|metal) =>", src)) == set(spira.SEMANTICS) == {"A", "cpu", "metal"}
+    ex, src = _julia_exports("Raytracer.jl")
+    # the functions of /root/reference/examples/julia-raytracer.jl that tests/bunny-test.jl:37-60 and the script's own main() call
+    assert {"Vec3", "Ray", "Material", "Sphere", "Triangle", "Mesh", "HittableList", "BoundingVolumeHierarchy", "Camera", "render", "to_acescg", "save_exr",
+            "load_obj_mesh", "create_scene", "create_scene_with_obj", "render_example"} <= ex
+    from spira_hip import raytracer
+    twin = {n for n in ("Vec3", "Material", "Sphere", "Triangle", "BoundingVolumeHierarchy", "Camera", "render", "to_acescg", "save_exr", "load_obj_mesh",
+                        "create_scene", "create_scene_with_obj", "flatten_world") if hasattr(raytracer, n)}
+    assert twin <= ex, twin - ex
+    for fn in ("function load_obj_mesh(filename::String, material::Material;", "function create_scene()", "function create_scene_with_obj(", "function render_example(;"):
+        assert fn in src, fn
+    # the vertex pipeline in the reference's order (:510-591): centre, normalise, rotate X / Y / Z, scale, translate
+    body = src[src.index("function load_obj_mesh"):src.index("example_camera() =")]
+    order = [body.index(k) for k in ("center_point", "1.0 / max_dimension", "rotation.x != 0\n", "rotation.y != 0\n", "rotation.z != 0\n", "v.x * scale.x", "v + translation")]
+    assert order == sorted(order)
+
+
+def test_both_julia_modules_refuse_a_library_of_another_abi_version():
+    for fname in ("SPIRA.jl", "Raytracer.jl"):
+        src = open(os.path.join(ROOT, "julia-spira_amd", "julia", fname)).read()
+        assert "const SPIRA_ABI_VERSION = 2" in src and "function __init__()" in src and "ccall((:spira_abi_version, libspira), Cint, ())" in src, fname
+    from spira_hip import _binding
+    assert _binding.ABI_VERSION == 2
+
+
+def test_flatten_world_gives_one_material_row_per_distinct_material(binding):
+    """A mesh shares one material (examples/julia-raytracer.jl:598): both hosts must give it ONE row of the table — a row per triangle
+    would need n x 64 bytes of LDS and fail with SPIRA_E_LIMIT above ~1 900 triangles."""
+    from spira_hip import raytracer as R
+    m = R.Material(diffuse=R.Vec3(0.7, 0.3, 0.2), specular=0.2, roughness=0.4)
+    tris = [R.Triangle([R.Vec3(i, 0, 0), R.Vec3(i + 1, 0, 0), R.Vec3(i, 1, 0)], m) for i in range(5000)]
+    world = R.BoundingVolumeHierarchy([R.Sphere(R.Vec3(0, -100.5, -1), 100, R.Material(diffuse=R.Vec3(0.8, 0.8, 0.2)))] + tris)
+    spheres5, materials8, triangles10 = R.flatten_world(world)
+    assert len(materials8) == 2 and len(triangles10) == 5000 and set(triangles10[:, 9]) == {2.0}
+    src = open(os.path.join(ROOT, "julia-spira_amd", "julia", "Raytracer.jl")).read()
+    body = src[src.index("function flatten_world"):src.index("aces1(x)")]
+    assert "Dict{Material,Int}()" in body and "get!(mat_index, m) do" in body      # the Julia twin dedupes by value (it cannot run here)
+
+
 def test_julia_png_and_exr_writers_mirror_the_python_ones(tmp_path):
     """The Julia file writers cannot run here; their byte layout is the Python writers' (spira_hip/png.py, exr.py), which CAN:
     PNG with stored deflate blocks decodes back, the EXR header matches the fields the Julia code emits."""

@@ -24,22 +24,67 @@ def test_algorithmic_bytes_per_organisation_and_precision():
     assert bench.algorithmic_bytes(c, 4, "bounce") == 2 * 40 * 400 + (3 * 1000 + 6 * 10) * 4
 
 
-def test_roofline_record_fields_and_bound():
+def test_roofline_record_fields_and_bound(tmp_path, monkeypatch):
     c = _counters(samples=132710400, segments=290665553, rays_enqueued=44000000, radiance_stores=132710400, radiance_rmw=300000, bounce_kernel_ms=5.6)
-    r = bench.roofline_record(c, "f64", "wavefront", "s1", True)
     nbytes = bench.algorithmic_bytes(c, 8, "wavefront")
+    # a PMC summary taken on THESE kernel sources is attached ...
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    fresh = {"kernel": "k_path", "source_hash": bench.kernel_source_hash(), "hbm_bytes_per_launch": 13.3e9,
+             "valu": {"busy_frac": 0.89, "lane_utilisation": 0.72, "simd_cycles_per_valu_inst": 4.5, "wave_cycle_shares": None, "priced_model": {"frac": 0.94, "other_share": 0.35}}}
+    json.dump(fresh, open(prof / "traffic_s1_f64.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: fresh["source_hash"])
+    r = bench.roofline_record(c, "f64", "wavefront", "s1", True)
     assert r["kernel"] == "k_path" and r["launches"] == 1 and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["achieved"] - nbytes / 5.6e-3 / 1e9) < 0.01 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
     assert r["avg_launch_ms"] * r["launches"] <= c["kernel_ms"]
-    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_s1_f64.json")))
-    assert tj["kernel"] == "k_path" and r["traffic"] == round(tj["hbm_bytes_per_launch"]) and r["valu"]["issue_frac"] == tj["valu"]["issue_frac"]
-    assert r["bound"] == ("valu" if tj["valu"]["issue_frac"] > r["frac"] else "hbm")
-    # not the headline shape: no PMC figures are attached
+    assert r["traffic"] == round(13.3e9) and r["traffic_stale"] is False and r["valu"]["busy_frac"] == 0.89 and r["valu"]["busy_frac"] <= 1.0
+    assert r["bound"] == "valu"
+    # ... one taken on other sources is not: no traffic, no VALU figures, no bound claimed, and the line says so
+    stale = dict(fresh, source_hash="0123456789abcdef")
+    json.dump(stale, open(prof / "traffic_s1_f64.json", "w"))
+    r1 = bench.roofline_record(c, "f64", "wavefront", "s1", True)
+    assert r1["traffic"] is None and r1["valu"] is None and r1["traffic_stale"] is True and r1["bound"] is None and "stale" in r1["traffic_source"]
+    # not the shape the summaries were taken on: nothing is attached
     r2 = bench.roofline_record(c, "f64", "wavefront", "s1", False)
-    assert r2["traffic"] is None and r2["valu"] is None and r2["bound"] == "hbm"
+    assert r2["traffic"] is None and r2["valu"] is None and r2["bound"] == "hbm" and r2["traffic_stale"] is False
+
+
+def test_committed_pmc_summaries_are_sane():
+    """No committed summary claims a busy fraction above 1 (a ceiling the kernel exceeds is not a ceiling)."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")):
+        tj = json.load(open(f))
+        v = tj.get("valu") or {}
+        if "busy_frac" in v:
+            assert 0.0 < v["busy_frac"] <= 1.0, f
+            assert "source_hash" in tj, f
 
 
 def test_configs_name_the_baseline_configurations():
-    assert bench.CONFIGS["c3"]["spp"] == 64 and bench.CONFIGS["c3"]["depth"] == 8 and bench.CONFIGS["c3"]["scaling"] == "weak"
-    assert bench.CONFIGS["c4"]["spp"] == 256 and bench.CONFIGS["c4"]["scaling"] == "strong"
+    assert bench.CONFIGS["c3"]["spp"] == 64 and bench.CONFIGS["c3"]["depth"] == 8 and bench.CONFIGS["c3"]["scaling"] == "weak" and bench.CONFIGS["c3"]["scene"] == "s1"
+    assert bench.CONFIGS["c4"]["spp"] == 256 and bench.CONFIGS["c4"]["scaling"] == "strong" and bench.CONFIGS["c4"]["scene"] == "s3"     # BASELINE.md §3
     assert bench.CONFIGS["c5"]["scene"] == "s4" and bench.CONFIGS["c5"]["depth"] == 12
+
+
+def test_metric_string_follows_the_workload():
+    assert bench.metric_string(1920, 1080, 64, 8) == "Msamples/sec at 1920x1080 spp=64 depth=8; fraction of HBM roofline"      # BASELINE.json's string
+    assert "depth=12" in bench.metric_string(1920, 1080, 64, 12) and "spp=256" in bench.metric_string(1920, 1080, 256, 8)
+
+
+def test_bench_line_keys_are_declared():
+    """The keys VERDICT r2 item 2 asks the driver-run line to carry are produced by main() (static check: no GPU here)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"configs": other_configs', '"end_to_end": end_to_end', '"roofline": roof', '"cpu_baseline": cpu', '"kernel_source_hash": src_hash',
+                'for cname in ("c4", "c5")', 'for pr in ("f64", "f32")', '"traffic_stale"'):
+        assert key in src, key
+
+
+def test_c4_tile_arithmetic_on_8_gpus():
+    """bench.py --config c4 --gpus 8: interleaved 8-row stripes give every rank 135 +- 1 rows... of 1080, and spp stays 256 in total."""
+    sys.path.insert(0, os.path.join(ROOT, "julia-spira_amd"))
+    from spira_hip import distributed as D
+    rows = [D.tile_params(1080, 8, r)["rows"] for r in range(8)]
+    assert sum(rows) == 1080 and max(rows) - min(rows) <= 8 and all(128 <= x <= 136 for x in rows)
+    assert bench.CONFIGS["c4"]["scaling"] == "strong"      # spp_total = spp (not spp * world): bench.py main()
