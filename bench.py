@@ -203,9 +203,23 @@ def main():
     # timed region; a step passes the camera and the parameters only
     scene_h = B.Scene(sc[0], sc[1], sc[2], args.prec)
 
-    def step():
+    step_events = []        # N > 1: (before render, after render, after gather) of every timed step, on the stream both are enqueued on
+
+    def step(timed=False):
+        if world == 1:
+            scene_h.render_device(sc[3], params, out.data_ptr(), 0, stream.cuda_stream)
+            return out
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        if ev:
+            ev[0].record(stream)
         scene_h.render_device(sc[3], params, out.data_ptr(), 0, stream.cuda_stream)
-        return D.gather_image(out, H) if world > 1 else out
+        if ev:
+            ev[1].record(stream)
+        img_ = D.gather_image(out, H)
+        if ev:
+            ev[2].record(stream)
+            step_events.append(ev)
+        return img_
 
     def fence():
         if world > 1:
@@ -220,13 +234,25 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        img = step()
+        img = step(timed=True)
     fence()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # where a scaling loss comes from: the slowest and the fastest rank's render (load balance between tiles) and gather (the one exchange;
+        # on the other ranks it includes waiting for the slowest renderer), per step, from events on this rank's stream — one all_reduce each
+        r_ms = sum(e[0].elapsed_time(e[1]) for e in step_events) / max(1, len(step_events))
+        g_ms = sum(e[1].elapsed_time(e[2]) for e in step_events) / max(1, len(step_events))
+        hi = torch.tensor([r_ms, g_ms], dtype=torch.float64, device="cuda")
+        lo = hi.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        per_rank = {"render_ms": {"max": round(float(hi[0]), 4), "min": round(float(lo[0]), 4)}, "gather_ms": {"max": round(float(hi[1]), 4), "min": round(float(lo[1]), 4)},
+                    "rows_per_rank": {"max": int(max(D.tile_params(H, world, r)["rows"] for r in range(world))), "min": int(min(D.tile_params(H, world, r)["rows"] for r in range(world)))},
+                    "what": "per step, over ranks: device time of the rank's tile render and of the gather that follows it (events on the rank's stream)"}
     c_timed = B.counters()          # device counters + event times of the LAST timed step on this rank
     samples_per_step = W * H * spp_total
     value = samples_per_step * args.steps / dt / 1e6
@@ -372,7 +398,7 @@ def main():
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
             "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "configs": other_configs, "other_precision": alt, "stress": stress,
-            "organisations": orgs, "estimators": estimators, "kernel_source_hash": src_hash,
+            "organisations": orgs, "estimators": estimators, "per_rank": per_rank, "kernel_source_hash": src_hash,
         }
         print(json.dumps(result), flush=True)
     scene_h.destroy()

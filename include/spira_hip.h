@@ -205,7 +205,11 @@ int spira_render_device_f64(const double *spheres5, const double *materials8, co
  * ncclSend / ncclRecv = a gather; n-1 point-to-point transfers over xGMI that arrive at device 0 at once) brings the tiles
  * to device 0, which permutes the rows back to image order and copies the frame to the caller's HOST buffers.
  * params->rows / stripe_* must be 0.  librccl.so.1 is opened at run time (the copy the process already carries, if any);
- * SPIRA_E_UNSUPPORTED when none can be found.  spira_get_counters afterwards reports device 0's tile. */
+ * SPIRA_E_UNSUPPORTED when none can be found; the communicators of a device count are made once (ncclCommInitAll) and kept
+ * until spira_shutdown.  Afterwards spira_get_counters reports the tile of the calling thread's current device
+ * (spira_set_device(d) first for device d's).  A failed exchange aborts the communicators and returns SPIRA_E_HIP: it never hangs.
+ * Status: one device through RCCL and n = 2, 3, 8 rehearsed on one device are tested; n > 1 on separate GPUs has not run yet
+ * (no multi-GPU box in the build pipeline). */
 int spira_render_multi_f32(const float *spheres5, const float *materials8, const float *triangles10,
                            const float camera12[12], const spira_params *params, int n_devices,
                            float *out_hdr, float *out_img);
@@ -226,6 +230,17 @@ int spira_scene_create_f32(const float *spheres5, const float *materials8, const
 int spira_scene_create_f64(const double *spheres5, const double *materials8, const double *triangles10,
                            uint32_t n_spheres, uint32_t n_materials, uint32_t n_triangles, spira_scene **out);
 int spira_scene_destroy(spira_scene *scene);       /* NULL is a no-op; waits for renders still using it */
+/* The same for spira_render_multi_*: ONE validation, ONE BVH build on the host, the scene resident on devices 0 .. n_devices-1
+ * (the host-array entry points re-validate, re-hash and, on first use, rebuild the tree per device per call).  The handle is
+ * device 0's; spira_scene_destroy frees all copies.  It also works with the single-device entry points on device 0. */
+int spira_scene_create_multi_f32(const float *spheres5, const float *materials8, const float *triangles10,
+                                 uint32_t n_spheres, uint32_t n_materials, uint32_t n_triangles, int n_devices, spira_scene **out);
+int spira_scene_create_multi_f64(const double *spheres5, const double *materials8, const double *triangles10,
+                                 uint32_t n_spheres, uint32_t n_materials, uint32_t n_triangles, int n_devices, spira_scene **out);
+int spira_render_multi_scene_f32(const spira_scene *scene, const float camera12[12], const spira_params *params, int n_devices,
+                                 float *out_hdr, float *out_img);
+int spira_render_multi_scene_f64(const spira_scene *scene, const double camera12[12], const spira_params *params, int n_devices,
+                                 double *out_hdr, double *out_img);
 int spira_render_scene_f32(const spira_scene *scene, const float camera12[12], const spira_params *params,
                            float *out_hdr, float *out_img);
 int spira_render_scene_f64(const spira_scene *scene, const double camera12[12], const spira_params *params,

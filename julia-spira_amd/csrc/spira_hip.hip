@@ -100,6 +100,9 @@ struct spira_scene {
     int device;
     int prec;              // sizeof(T) the scene was created in
     SceneStore store;
+    // spira_scene_create_multi_*: the same scene resident on devices 1 .. n_replicas-1 as well (this handle is device 0's)
+    int n_replicas = 1;
+    spira_scene *replica[16] = {};
 };
 
 namespace {
@@ -239,12 +242,30 @@ void scene_pointers(const SceneStore &s, spira::SceneGlobal<T> &g) {
     g.bvh_slots = use_bvh ? s.bvh_slots : 0;
 }
 
+// A mesh's tree as built on the host: one build can be uploaded to several devices (spira_scene_create_multi_*).
+template <class T> struct HostBvh {
+    std::vector<uint32_t> nodes;
+    std::vector<spira::HostPack4<T>> tris;
+    spira::HostPack4<T> frame[3];
+    uint32_t slots = 0; int depth = 0; bool built = false;
+};
+template <class T>
+int host_bvh_build(const T *triangles10, uint32_t nt, HostBvh<T> &hb) {
+    spira::BvhFrame<T> fr{};
+    if (!spira::bvh_build<T>(triangles10, nt, hb.nodes, hb.tris, fr, std::min<uint32_t>(spira::kBvhLeafTris, std::max<uint32_t>(1, env_u32("SPIRA_BVH_LEAF", 1)))))
+        return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
+    hb.frame[0] = {fr.root_mn[0], fr.root_mn[1], fr.root_mn[2], (T)0}; hb.frame[1] = {fr.root_mx[0], fr.root_mx[1], fr.root_mx[2], (T)0};
+    hb.frame[2] = {fr.centre[0], fr.centre[1], fr.centre[2], fr.scale};
+    hb.slots = fr.n_slots; hb.depth = fr.depth; hb.built = true;
+    return 0;
+}
+
 // Upload host arrays into `s`.  The small arrays go asynchronously on `st`; a mesh above SPIRA_LDS_TRIANGLES gets a
 // BVH built on the host (once per distinct triangle array: keyed by a hash of its bytes) and copied synchronously —
 // `prev_done` (the event of the last call that may still be traversing the old tree) is waited for first.
 template <class T>
 int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *spheres5, const T *materials8, const T *triangles10,
-                 uint32_t n_spheres, uint32_t n_materials, uint32_t nt) {
+                 uint32_t n_spheres, uint32_t n_materials, uint32_t nt, HostBvh<T> *shared = nullptr) {
     const bool use_bvh = nt > SPIRA_LDS_TRIANGLES;
     const uint32_t nt_lds = use_bvh ? 0 : nt;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -260,23 +281,20 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
     if (use_bvh) {
         const uint64_t h = spira::bytes_hash64(triangles10, (size_t)nt * 10 * sizeof(T));
         if (s.bvh_hash != h || s.bvh_n != nt || s.bvh_prec != (int)sizeof(T)) {
-            std::vector<uint32_t> nodes;
-            std::vector<spira::HostPack4<T>> tris;
-            spira::BvhFrame<T> fr{};
-            if (!spira::bvh_build<T>(triangles10, nt, nodes, tris, fr, std::min<uint32_t>(spira::kBvhLeafTris, std::max<uint32_t>(1, env_u32("SPIRA_BVH_LEAF", 1))))) return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
-            const spira::HostPack4<T> frame[3] = {{fr.root_mn[0], fr.root_mn[1], fr.root_mn[2], (T)0}, {fr.root_mx[0], fr.root_mx[1], fr.root_mx[2], (T)0},
-                                                  {fr.centre[0], fr.centre[1], fr.centre[2], fr.scale}};
+            HostBvh<T> local;
+            HostBvh<T> &hb = shared ? *shared : local;
+            if (!hb.built) { if (int rc = host_bvh_build<T>(triangles10, nt, hb)) return rc; }
             if (prev_done) HIP_TRY(hipEventSynchronize(prev_done));      // nobody still reads the tree that is about to be replaced
             // (+ one record of padding each: a walk's trip loads 5 / 6 x 16 bytes from a node or a triangle alike, spira_device.h bvh8_step)
-            if (int rc = s.bvh_nodes.ensure(nodes.size() * sizeof(nodes[0]) + 128)) return rc;
-            if (int rc = s.bvh_tris.ensure(sizeof frame + tris.size() * sizeof(tris[0]) + 128)) return rc;
-            // synchronous copies: the host vectors die at the end of this scope
+            if (int rc = s.bvh_nodes.ensure(hb.nodes.size() * sizeof(hb.nodes[0]) + 128)) return rc;
+            if (int rc = s.bvh_tris.ensure(sizeof hb.frame + hb.tris.size() * sizeof(hb.tris[0]) + 128)) return rc;
+            // synchronous copies: the host vectors may die at the end of this scope
             HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipMemcpy(s.bvh_nodes.p, nodes.data(), nodes.size() * sizeof(nodes[0]), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(s.bvh_tris.p, frame, sizeof frame, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy((char *)s.bvh_tris.p + sizeof frame, tris.data(), tris.size() * sizeof(tris[0]), hipMemcpyHostToDevice));
-            const int depth = fr.depth;
-            s.bvh_slots = fr.n_slots;
+            HIP_TRY(hipMemcpy(s.bvh_nodes.p, hb.nodes.data(), hb.nodes.size() * sizeof(hb.nodes[0]), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(s.bvh_tris.p, hb.frame, sizeof hb.frame, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy((char *)s.bvh_tris.p + sizeof hb.frame, hb.tris.data(), hb.tris.size() * sizeof(hb.tris[0]), hipMemcpyHostToDevice));
+            const int depth = hb.depth;
+            s.bvh_slots = hb.slots;
             s.bvh_hash = h; s.bvh_n = nt; s.bvh_prec = (int)sizeof(T); s.bvh_depth = depth;
         }
     }
@@ -851,22 +869,47 @@ void camera_impl(const T *position, const T *look_at, const T *up, T fov_deg, T 
     std::memcpy(out12, o, sizeof o);
 }
 
+// n_devices == 0: a handle on the calling thread's device; n_devices >= 1: one validated and built ONCE, resident on devices 0 .. n_devices-1
 template <class T>
 int scene_create(const T *spheres5, const T *materials8, const T *triangles10, uint32_t n_spheres, uint32_t n_materials,
-                        uint32_t n_triangles, spira_scene **out) {
+                        uint32_t n_triangles, spira_scene **out, int n_devices = 0) {
     if (!out) return fail(SPIRA_E_INVALID, "out is NULL");
     *out = nullptr;
     const uint32_t nt = triangles10 ? n_triangles : 0;
     if (int rc = validate_scene<T>(spheres5, materials8, triangles10, n_spheres, n_materials, nt)) return rc;
-    Ctx *cp = nullptr;
-    if (int rc = get_ctx(&cp)) return rc;              // also selects the device
-    spira_scene *h = new (std::nothrow) spira_scene();
-    if (!h) return fail(SPIRA_E_HIP, "out of host memory");
-    h->magic = kSceneMagic; h->device = tl_device; h->prec = (int)sizeof(T);
-    int rc = scene_upload<T>(h->store, nullptr, nullptr, spheres5, materials8, triangles10, n_spheres, n_materials, nt);
-    if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(SPIRA_E_HIP, "hipStreamSynchronize failed after the scene upload");
-    if (rc) { h->store.release(); h->magic = 0; delete h; return rc; }
-    *out = h;
+    const bool multi = n_devices > 0;
+    if (multi && (n_devices > kMaxDevices || (n_devices > spira_device_count() && !env_u32("SPIRA_MULTI_REHEARSE", 0))))
+        return fail(SPIRA_E_INVALID, "n_devices out of range (1 .. spira_device_count())");
+    const int caller_device = tl_device;
+    const int n_phys = multi ? std::min(n_devices, std::max(1, spira_device_count())) : 1;      // (rehearsal: every rank renders on device 0)
+    HostBvh<T> hb;                                      // the mesh's tree: built on the first upload, reused by the others
+    spira_scene *first = nullptr;
+    int rc = 0;
+    for (int d = 0; d < n_phys && !rc; ++d) {
+        if (multi) tl_device = d;
+        Ctx *cp = nullptr;
+        if ((rc = get_ctx(&cp))) break;                // also selects the device
+        spira_scene *h = new (std::nothrow) spira_scene();
+        if (!h) { rc = fail(SPIRA_E_HIP, "out of host memory"); break; }
+        h->magic = kSceneMagic; h->device = tl_device; h->prec = (int)sizeof(T);
+        if (!first) first = h; else { first->replica[d] = h; }
+        rc = scene_upload<T>(h->store, nullptr, nullptr, spheres5, materials8, triangles10, n_spheres, n_materials, nt, &hb);
+        if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(SPIRA_E_HIP, "hipStreamSynchronize failed after the scene upload");
+        if (!rc) first->n_replicas = d + 1;
+    }
+    tl_device = caller_device;
+    (void)hipSetDevice(caller_device);
+    if (rc) {
+        const std::string keep = tl_err;
+        if (first) {
+            for (int d = 1; d < kMaxDevices; ++d) if (first->replica[d]) { (void)hipSetDevice(first->replica[d]->device); first->replica[d]->store.release(); first->replica[d]->magic = 0; delete first->replica[d]; }
+            (void)hipSetDevice(first->device); first->store.release(); first->magic = 0; delete first;
+            (void)hipSetDevice(caller_device);
+        }
+        tl_err = keep;
+        return rc;
+    }
+    *out = first;
     return 0;
 }
 
@@ -878,13 +921,17 @@ struct Rccl {
     void *handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    int n = 0;                           // communicators currently held (devices 0..n-1)
-    ncclComm_t comms[kMaxDevices] = {};
+    // one set of communicators per device count ever asked for (devices 0..n-1), kept until spira_shutdown: a host that alternates
+    // between, say, 8-GPU frames and 4-GPU previews does not pay ncclCommInitAll (hundreds of ms) at every switch
+    bool have[kMaxDevices + 1] = {};
+    ncclComm_t comms_of[kMaxDevices + 1][kMaxDevices] = {};
+    ncclComm_t *comms = nullptr;         // the set of the current call
     std::mutex mu;
 };
 Rccl g_rccl;
@@ -901,6 +948,7 @@ int rccl_load(Rccl &r) {
     if (!r.field) { r.handle = nullptr; return fail(SPIRA_E_UNSUPPORTED, "RCCL symbol missing: " #sym); }
     SPIRA_RCCL_SYM(CommInitAll, ncclCommInitAll)
     SPIRA_RCCL_SYM(CommDestroy, ncclCommDestroy)
+    SPIRA_RCCL_SYM(CommAbort, ncclCommAbort)
     SPIRA_RCCL_SYM(GroupStart, ncclGroupStart)
     SPIRA_RCCL_SYM(GroupEnd, ncclGroupEnd)
     SPIRA_RCCL_SYM(Send, ncclSend)
@@ -911,19 +959,32 @@ int rccl_load(Rccl &r) {
 }
 
 void rccl_release(Rccl &r) {
-    for (int i = 0; i < r.n; ++i) if (r.comms[i]) { (void)r.CommDestroy(r.comms[i]); r.comms[i] = nullptr; }
-    r.n = 0;
+    for (int n = 1; n <= kMaxDevices; ++n) {
+        if (!r.have[n]) continue;
+        for (int i = 0; i < n; ++i) if (r.comms_of[n][i]) { (void)r.CommDestroy(r.comms_of[n][i]); r.comms_of[n][i] = nullptr; }
+        r.have[n] = false;
+    }
+    r.comms = nullptr;
+}
+
+// after a failed exchange: the communicators of this device count may hold a half-issued group — abort them, the next call makes new ones
+void rccl_abort(Rccl &r, int n) {
+    if (!r.have[n]) return;
+    for (int i = 0; i < n; ++i) if (r.comms_of[n][i]) { (void)r.CommAbort(r.comms_of[n][i]); r.comms_of[n][i] = nullptr; }
+    r.have[n] = false;
+    r.comms = nullptr;
 }
 
 int rccl_comms(Rccl &r, int n) {          // communicators for devices 0..n-1 (ncclCommInitAll once per n)
     if (int rc = rccl_load(r)) return rc;
-    if (r.n == n) return 0;
-    rccl_release(r);
-    int devs[kMaxDevices];
-    for (int i = 0; i < n; ++i) devs[i] = i;
-    ncclResult_t e = r.CommInitAll(r.comms, n, devs);
-    if (e != ncclSuccess) return fail(SPIRA_E_HIP, std::string("ncclCommInitAll: ") + r.GetErrorString(e));
-    r.n = n;
+    if (!r.have[n]) {
+        int devs[kMaxDevices];
+        for (int i = 0; i < n; ++i) devs[i] = i;
+        ncclResult_t e = r.CommInitAll(r.comms_of[n], n, devs);
+        if (e != ncclSuccess) return fail(SPIRA_E_HIP, std::string("ncclCommInitAll: ") + r.GetErrorString(e));
+        r.have[n] = true;
+    }
+    r.comms = r.comms_of[n];
     return 0;
 }
 
@@ -945,8 +1006,9 @@ __global__ void k_assemble(const T *stack, T *full, uint32_t n, uint32_t stripe_
 
 constexpr uint32_t kMultiStripeH = 8;
 
+// `mh`: a scene resident on the devices (spira_scene_create_multi_*) — nothing is validated, hashed, built or uploaded per call — or NULL: host arrays
 template <class T>
-int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p, int n_devices,
+int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p, int n_devices,
                       T *out_hdr, T *out_img) {
     if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
     if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
@@ -958,7 +1020,13 @@ int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles
     if (n_devices < 1 || n_devices > kMaxDevices || (!rehearse && n_devices > avail)) return fail(SPIRA_E_INVALID, "n_devices out of range (1 .. spira_device_count())");
     if (avail < 1) return fail(SPIRA_E_NO_DEVICE, "no HIP device");
     // validate once on the calling thread, so that argument errors are reported before any thread or communicator exists
-    {
+    if (mh) {
+        if (mh->magic != kSceneMagic) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+        if (mh->prec != (int)sizeof(T)) return fail(SPIRA_E_INVALID, "scene handle was created in the other precision");
+        if (mh->device != 0 || (!rehearse && mh->n_replicas < n_devices)) return fail(SPIRA_E_INVALID, "scene handle is not resident on devices 0 .. n_devices-1 (spira_scene_create_multi_*)");
+        uint32_t rows = 0;
+        if (int rc = validate_params(camera12, p, mh->store.nt, &rows)) return rc;
+    } else {
         uint32_t rows = 0;
         const uint32_t nt = triangles10 ? p->n_triangles : 0;
         if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, nt)) return rc;
@@ -973,6 +1041,7 @@ int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles
 
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
+    bool exchange_failed = false;
     const int caller_device = tl_device;
     // Every device finishes (or fails) its allocation + render-enqueue phase before any of them enters the exchange: a device that
     // failed early must not leave device 0 waiting on the stream for a tile that will never be sent.
@@ -980,11 +1049,13 @@ int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles
     std::condition_variable gate_cv;
     uint32_t gate_arrived = 0;
     bool gate_failed = false;
-    auto gate = [&](bool ok) -> bool {        // returns whether ALL devices got here without an error
+    uint32_t gate_round = 0;
+    auto gate = [&](bool ok) -> bool {        // returns whether ALL devices got here without an error (reusable: the exchange has one behind it too)
         std::unique_lock<std::mutex> lk(gate_mu);
         if (!ok) gate_failed = true;
-        if (++gate_arrived == n) gate_cv.notify_all();
-        else gate_cv.wait(lk, [&] { return gate_arrived == n; });
+        const uint32_t my_round = gate_round;
+        if (++gate_arrived == n) { gate_arrived = 0; ++gate_round; gate_cv.notify_all(); }
+        else gate_cv.wait(lk, [&] { return gate_round != my_round; });
         return !gate_failed;
     };
     auto worker = [&](uint32_t r) {
@@ -1013,15 +1084,16 @@ int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles
             // render_impl writes each output as [3][rows][W] contiguously; the gather wants every tile at the pitch of the largest one
             // ([6][max_rows][W]).  A tile with fewer rows (ragged last stripes) is rendered into the second half of the buffer and its
             // six planes are re-pitched with one strided device copy.
+            const spira_scene *hr = !mh ? nullptr : ((rehearse || r == 0) ? mh : mh->replica[r]);
             if (rows_r_all != max_rows) {
                 T *scratch = d_hdr + tile_elems;
-                if (int rc = render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, scratch, scratch + (size_t)3 * rows_r_all * W, true, st)) return rc;
+                if (int rc = render_impl<T>(hr, spheres5, materials8, triangles10, camera12, &tp, scratch, scratch + (size_t)3 * rows_r_all * W, true, st)) return rc;
                 hipError_t e = hipMemcpy2DAsync(d_hdr, (size_t)max_rows * W * sizeof(T), scratch, (size_t)rows_r_all * W * sizeof(T), (size_t)rows_r_all * W * sizeof(T), 6,
                                                 hipMemcpyDeviceToDevice, st);
                 if (e != hipSuccess) return fail(SPIRA_E_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e));
                 return 0;
             }
-            return render_impl<T>(nullptr, spheres5, materials8, triangles10, camera12, &tp, d_hdr, d_img, true, st);
+            return render_impl<T>(hr, spheres5, materials8, triangles10, camera12, &tp, d_hdr, d_img, true, st);
         };
         const int rc1 = phase1();
         if (rc1) bail(rc1);
@@ -1042,7 +1114,10 @@ int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles
                 e = g_rccl.Recv((T *)c.multi_stack.p + (size_t)src * tile_elems, tile_elems, dt, (int)src, g_rccl.comms[0], st);
         ncclResult_t e2 = g_rccl.GroupEnd();
         if (e == ncclSuccess) e = e2;
-        if (e != ncclSuccess) { tl_err = std::string("RCCL gather: ") + g_rccl.GetErrorString(e); return bail(SPIRA_E_HIP); }
+        if (e != ncclSuccess) { tl_err = std::string("RCCL gather: ") + g_rccl.GetErrorString(e); bail(SPIRA_E_HIP); }
+        // A rank whose send could not be issued leaves device 0's receive waiting for ever: every rank learns here whether ALL of them
+        // issued their part, and when one did not, nobody synchronises on the exchange — the communicators are aborted after the threads join.
+        if (!gate(e == ncclSuccess)) { exchange_failed = true; return; }
         }
         if (rehearse || r == 0) {
             const uint32_t blocks = (uint32_t)std::min<size_t>(((size_t)6 * H * W + 255) / 256, (size_t)c.num_cus * 16);
@@ -1070,8 +1145,10 @@ int render_multi_impl(const T *spheres5, const T *materials8, const T *triangles
     }
     tl_device = caller_device;
     (void)hipSetDevice(caller_device);
+    if (exchange_failed) rccl_abort(g_rccl, n_devices);
     for (uint32_t r = 0; r < n; ++r)
         if (rcs[r]) return fail(rcs[r], "device " + std::to_string(r) + ": " + errs[r]);
+    if (exchange_failed) return fail(SPIRA_E_HIP, "RCCL gather failed on another device");
     return 0;
 }
 
@@ -1217,13 +1294,36 @@ int spira_scene_create_f64(const double *spheres5, const double *materials8, con
                            uint32_t n_triangles, spira_scene **out) {
     return scene_create<double>(spheres5, materials8, triangles10, n_spheres, n_materials, n_triangles, out);
 }
+int spira_scene_create_multi_f32(const float *spheres5, const float *materials8, const float *triangles10, uint32_t n_spheres, uint32_t n_materials,
+                                 uint32_t n_triangles, int n_devices, spira_scene **out) {
+    if (n_devices < 1) return fail(SPIRA_E_INVALID, "n_devices out of range (1 .. spira_device_count())");
+    return scene_create<float>(spheres5, materials8, triangles10, n_spheres, n_materials, n_triangles, out, n_devices);
+}
+int spira_scene_create_multi_f64(const double *spheres5, const double *materials8, const double *triangles10, uint32_t n_spheres, uint32_t n_materials,
+                                 uint32_t n_triangles, int n_devices, spira_scene **out) {
+    if (n_devices < 1) return fail(SPIRA_E_INVALID, "n_devices out of range (1 .. spira_device_count())");
+    return scene_create<double>(spheres5, materials8, triangles10, n_spheres, n_materials, n_triangles, out, n_devices);
+}
+int spira_render_multi_scene_f32(const spira_scene *scene, const float cam[12], const spira_params *p, int n_devices, float *out_hdr, float *out_img) {
+    if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+    return render_multi_impl<float>(scene, nullptr, nullptr, nullptr, cam, p, n_devices, out_hdr, out_img);
+}
+int spira_render_multi_scene_f64(const spira_scene *scene, const double cam[12], const spira_params *p, int n_devices, double *out_hdr, double *out_img) {
+    if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
+    return render_multi_impl<double>(scene, nullptr, nullptr, nullptr, cam, p, n_devices, out_hdr, out_img);
+}
 int spira_scene_destroy(spira_scene *scene) {
     if (!scene) return 0;
     if (scene->magic != kSceneMagic) return fail(SPIRA_E_INVALID, "scene handle was already destroyed");
-    if (hipSetDevice(scene->device) != hipSuccess) return fail(SPIRA_E_HIP, "hipSetDevice failed");
-    scene->store.release();                            // hipFree waits for work that still reads the buffers
-    scene->magic = 0;
-    delete scene;
+    for (int d = kMaxDevices - 1; d >= 0; --d) {           // the replicas of a multi-device handle first, then the handle itself
+        spira_scene *h = d ? scene->replica[d] : scene;
+        if (!h) continue;
+        if (hipSetDevice(h->device) != hipSuccess) return fail(SPIRA_E_HIP, "hipSetDevice failed");
+        h->store.release();                                // hipFree waits for work that still reads the buffers
+        h->magic = 0;
+        delete h;
+    }
+    (void)hipSetDevice(tl_device);
     return 0;
 }
 int spira_render_scene_f32(const spira_scene *scene, const float cam[12], const spira_params *p, float *out_hdr, float *out_img) {
@@ -1246,11 +1346,11 @@ int spira_render_scene_device_f64(const spira_scene *scene, const double cam[12]
 // ---- multi-device render on one node: interleaved 8-row stripes, one host thread + stream per device, one RCCL gather
 int spira_render_multi_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, int n_devices,
                            float *out_hdr, float *out_img) {
-    return render_multi_impl<float>(s, m, t, cam, p, n_devices, out_hdr, out_img);
+    return render_multi_impl<float>(nullptr, s, m, t, cam, p, n_devices, out_hdr, out_img);
 }
 int spira_render_multi_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, int n_devices,
                            double *out_hdr, double *out_img) {
-    return render_multi_impl<double>(s, m, t, cam, p, n_devices, out_hdr, out_img);
+    return render_multi_impl<double>(nullptr, s, m, t, cam, p, n_devices, out_hdr, out_img);
 }
 
 int spira_trace_paths_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t n_paths,

@@ -31,7 +31,8 @@ EXPORTS = [
     "spira_tonemap_f32", "spira_stripe_rows", "spira_accumulate_f32", "spira_accumulate_f64", "spira_accumulate_device_f32",
     "spira_accumulate_device_f64", "spira_scene_create_f32", "spira_scene_create_f64", "spira_scene_destroy",
     "spira_render_scene_f32", "spira_render_scene_f64", "spira_render_scene_device_f32", "spira_render_scene_device_f64",
-    "spira_render_multi_f32", "spira_render_multi_f64",
+    "spira_render_multi_f32", "spira_render_multi_f64", "spira_scene_create_multi_f32", "spira_scene_create_multi_f64",
+    "spira_render_multi_scene_f32", "spira_render_multi_scene_f64",
 ]
 
 
@@ -192,16 +193,33 @@ class Scene:
     """A scene resident on the current device (spira_scene_create_* / spira_scene_destroy): validated, its BVH built
     and everything uploaded once.  Use as a context manager or call destroy()."""
 
-    def __init__(self, spheres5, materials8, triangles10=None, prec="f32"):
+    def __init__(self, spheres5, materials8, triangles10=None, prec="f32", n_devices=0):
+        """n_devices >= 1: spira_scene_create_multi_* — validated and built once, resident on devices 0 .. n_devices-1 (render_multi)."""
         npdt, _ = _dt(prec)
         s, sp = _arr(spheres5, npdt)
         m, mp = _arr(materials8, npdt)
         t, tp = _arr(triangles10, npdt)
         self.prec = prec
+        self.n_devices = n_devices
         self.counts = (0 if s is None else len(s), len(m), 0 if t is None else len(t))
         self._h = C.c_void_p()
-        fn = lib().spira_scene_create_f32 if prec == "f32" else lib().spira_scene_create_f64
-        _check(fn(sp, mp, tp, C.c_uint32(self.counts[0]), C.c_uint32(self.counts[1]), C.c_uint32(self.counts[2]), C.byref(self._h)))
+        if n_devices:
+            fn = lib().spira_scene_create_multi_f32 if prec == "f32" else lib().spira_scene_create_multi_f64
+            _check(fn(sp, mp, tp, C.c_uint32(self.counts[0]), C.c_uint32(self.counts[1]), C.c_uint32(self.counts[2]), C.c_int(n_devices), C.byref(self._h)))
+        else:
+            fn = lib().spira_scene_create_f32 if prec == "f32" else lib().spira_scene_create_f64
+            _check(fn(sp, mp, tp, C.c_uint32(self.counts[0]), C.c_uint32(self.counts[1]), C.c_uint32(self.counts[2]), C.byref(self._h)))
+
+    def render_multi(self, camera12, params, n_devices=None, want_hdr=True, want_img=False):
+        """spira_render_multi_scene_*: the frame on n_devices GPUs from the resident copies of this scene, host outputs."""
+        npdt, _ = _dt(self.prec)
+        c, cp = _arr(camera12, npdt)
+        hdr = np.empty((3, params.height, params.width), dtype=npdt) if want_hdr else None
+        img = np.empty((3, params.height, params.width), dtype=npdt) if want_img else None
+        fn = lib().spira_render_multi_scene_f32 if self.prec == "f32" else lib().spira_render_multi_scene_f64
+        _check(fn(self._h, cp, C.byref(params), C.c_int(n_devices or self.n_devices), hdr.ctypes.data_as(C.c_void_p) if want_hdr else None,
+                  img.ctypes.data_as(C.c_void_p) if want_img else None))
+        return hdr, img
 
     def destroy(self):
         if self._h:

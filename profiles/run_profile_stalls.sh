@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes for the "where do wave-cycles go" question on k_bounce (issue vs wait vs dependency stalls).
+# PMC passes for the "where do wave-cycles go" question on the dominant kernel — k_path (default organisation), k_path_metal, k_bounce —
+# (issue vs wait vs dependency stalls).
 # usage: profiles/run_profile_stalls.sh <tag> [extra bench.py args]
 set -u
 TAG=${1:-stalls}; shift || true
@@ -21,8 +22,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(out + "/pmc_w*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "k_bounce" not in k: continue
-        k = k[k.index("k_bounce"):k.index("(")] if "(" in k else k
+        dom = next((d for d in ("k_path_metal", "k_path", "k_bounce") if d in k), None)      # whichever organisation the bench command ran
+        if dom is None: continue
+        k = k[k.index(dom):k.index("(")] if "(" in k else k
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
 json.dump(agg, open(out + "/stalls.json", "w"), indent=1)
 for k, v in agg.items():
