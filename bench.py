@@ -114,15 +114,15 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape, source_hash=None)
         else:
             rec["traffic"], rec["traffic_source"] = round(tj["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(tfile)
             v = tj.get("valu")
-            if v and v.get("busy_frac"):
-                rec["valu"] = {"busy_frac": v["busy_frac"], "lane_utilisation": v["lane_utilisation"], "simd_cycles_per_valu_inst": v["simd_cycles_per_valu_inst"],
-                               "wave_cycle_shares": v.get("wave_cycle_shares"), "priced_model": v.get("priced_model"),
-                               "what": "measured by PMC on this same command (rocprofv3 --pmc passes, profiles/run_profile.sh): busy_frac = 4 x SQ_ACTIVE_INST_VALU "
-                                       "(quad-cycles) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = the share of SIMD cycles in which a VALU instruction executes; "
-                                       "lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); priced_model (secondary) = instruction counts per "
-                                       "class x the issue cost of each class (profiles/microbench/valu_peak.hip), with the share of instructions no class counter covers",
+            if v and v.get("issue_slots"):
+                rec["valu"] = {"issue_slots": v["issue_slots"], "simd_cycles_per_valu_inst": v["simd_cycles_per_valu_inst"], "lane_utilisation": v["lane_utilisation"],
+                               "wave_cycle_shares": v.get("wave_cycle_shares"), "valubusy_rocprof": v.get("valubusy_rocprof"),
+                               "what": "measured by PMC on this same command (rocprofv3 --pmc passes, profiles/run_profile.sh): issue_slots = 2 issue passes x VALU "
+                                       "wave-instructions / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) — a hard-bounded share of the VALU issue port that understates "
+                                       "Float64 / transcendental instructions (they hold the port 4.7-16 cycles); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x "
+                                       "SQ_ACTIVE_INST_VALU); valubusy_rocprof = rocprof's VALUBusy, which charges 4 cycles per instruction and exceeds 1 on Float32",
                                "source": rec["traffic_source"]}
-                if v["busy_frac"] > rec["frac"]:
+                if v["issue_slots"] > rec["frac"]:
                     rec["bound"] = "valu"
     return rec
 

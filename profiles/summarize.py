@@ -168,7 +168,7 @@ def main():
             simd_cycles = 1024 * tot("GRBM_GUI_ACTIVE") / 8
             # the class counters come from other passes of the same (deterministic) command: scale them to this pass's dispatch count
             n_disp = max(1, launches_of("SQ_INSTS_VALU"))
-            mix, covered, weighted = {}, 0.0, 0.0
+            mix, covered = {}, 0.0
             for cname, cost in VALU_COST.items():
                 if cname.startswith("other"):
                     continue
@@ -177,24 +177,24 @@ def main():
                     cnt = tot(cname) * n_disp / nd
                     mix[cname.replace("SQ_INSTS_VALU_", "").lower()] = round(cnt / n_inst, 4)
                     covered += cnt
-                    weighted += cnt * cost * MICROBENCH_CLOCK_GHZ / 2.4
-            priced = None
             if mix:
-                other = VALU_COST["other_f64"] if mix.get("fma_f64", 0) > mix.get("fma_f32", 0) else VALU_COST["other_f32"]
-                weighted += max(0.0, n_inst - covered) * other * MICROBENCH_CLOCK_GHZ / 2.4
                 mix["other"] = round(max(0.0, n_inst - covered) / n_inst, 4)
-                priced = {"frac": round(weighted / simd_cycles, 4), "modelled_cycles_per_valu_inst": round(weighted / n_inst, 3), "mix": mix,
-                          "other_share": mix["other"], "issue_cost_table": VALU_COST,
-                          "note": "a model, not a measurement: the share of instructions no class counter covers is priced with one average (+-8 %)"}
-            # MEASURED: SQ_ACTIVE_INST_VALU counts quad-cycles in which a VALU instruction executes, summed over the SIMDs
+            # MEASURED.  issue_slots = VALU wave-instructions x the 2 issue passes each needs at least (MI355X_MICROARCH.md) over the SIMD cycles
+            # of the same dispatches: a hard-bounded (<= 1) share of the VALU issue port; Float64 and transcendental instructions hold the port
+            # longer (profiles/r02_valu_peak.txt: 4.7-5.4 and 8-16 cycles), so it understates a Float64 kernel — simd_cycles_per_valu_inst next
+            # to it says how far from 2 the kernel's mix can be at best.  valubusy_rocprof is rocprof's derived VALUBusy, 4 x SQ_ACTIVE_INST_VALU
+            # / (SIMDs x cycles): on this chip SQ_ACTIVE_INST_VALU comes out at one quad-cycle per instruction (~= SQ_INSTS_VALU), i.e. the metric
+            # charges 4 cycles to every instruction and reads ABOVE 1 on Float32 kernels (1.08-1.21) — listed for reference, not a ceiling.
+            # (Round 2's priced model — instruction classes x microbenchmarked issue costs — is gone: a third of the instructions belong to no
+            # class counter, and pricing them with one average put it above 1.)
             busy = 4.0 * tot("SQ_ACTIVE_INST_VALU") / simd_cycles
-            out["valu"] = {"busy_frac": round(busy, 4), "simd_cycles_per_valu_inst": round(simd_cycles / n_inst, 3),
+            out["valu"] = {"issue_slots": round(2.0 * n_inst / simd_cycles, 4), "valubusy_rocprof": round(busy, 4), "simd_cycles_per_valu_inst": round(simd_cycles / n_inst, 3),
                            "effective_clock_GHz": round(tot("GRBM_GUI_ACTIVE") / 8 / max(wall_ns, 1.0), 3),
                            "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / max(1.0, 64 * tot("SQ_ACTIVE_INST_VALU")), 4),
                            "valu_insts_per_launch": tot("SQ_INSTS_VALU") / max(1, launches_of("SQ_INSTS_VALU")),
                            "wave_cycle_shares": {"wait_any": round(tot("SQ_WAIT_ANY") / w, 3), "wait_inst_any": round(tot("SQ_WAIT_INST_ANY") / w, 3),
                                                  "active_inst_any": round(tot("SQ_ACTIVE_INST_ANY") / w, 3)} if w else None,
-                           "priced_model": priced}
+                           "instruction_mix": mix or None}
         json.dump(out, open(os.path.splitext(dst)[0] + ".json", "w"), indent=1)
         break
     open(dst, "w").write("\n".join(lines) + "\n")

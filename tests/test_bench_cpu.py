@@ -31,7 +31,7 @@ def test_roofline_record_fields_and_bound(tmp_path, monkeypatch):
     prof = tmp_path / "profiles"
     prof.mkdir()
     fresh = {"kernel": "k_path", "source_hash": bench.kernel_source_hash(), "hbm_bytes_per_launch": 13.3e9,
-             "valu": {"busy_frac": 0.89, "lane_utilisation": 0.72, "simd_cycles_per_valu_inst": 4.5, "wave_cycle_shares": None, "priced_model": {"frac": 0.94, "other_share": 0.35}}}
+             "valu": {"issue_slots": 0.43, "valubusy_rocprof": 0.89, "lane_utilisation": 0.72, "simd_cycles_per_valu_inst": 4.5, "wave_cycle_shares": None}}
     json.dump(fresh, open(prof / "traffic_s1_f64.json", "w"))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     monkeypatch.setattr(bench, "kernel_source_hash", lambda: fresh["source_hash"])
@@ -39,7 +39,7 @@ def test_roofline_record_fields_and_bound(tmp_path, monkeypatch):
     assert r["kernel"] == "k_path" and r["launches"] == 1 and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["achieved"] - nbytes / 5.6e-3 / 1e9) < 0.01 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
     assert r["avg_launch_ms"] * r["launches"] <= c["kernel_ms"]
-    assert r["traffic"] == round(13.3e9) and r["traffic_stale"] is False and r["valu"]["busy_frac"] == 0.89 and r["valu"]["busy_frac"] <= 1.0
+    assert r["traffic"] == round(13.3e9) and r["traffic_stale"] is False and r["valu"]["issue_slots"] == 0.43 and r["valu"]["issue_slots"] <= 1.0
     assert r["bound"] == "valu"
     # ... one taken on other sources is not: no traffic, no VALU figures, no bound claimed, and the line says so
     stale = dict(fresh, source_hash="0123456789abcdef")
@@ -52,13 +52,15 @@ def test_roofline_record_fields_and_bound(tmp_path, monkeypatch):
 
 
 def test_committed_pmc_summaries_are_sane():
-    """No committed summary claims a busy fraction above 1 (a ceiling the kernel exceeds is not a ceiling)."""
+    """The committed summaries carry measured figures only (a modelled ceiling the kernel exceeds is not a ceiling): the share of VALU
+    issue slots is <= 1 by construction, no priced model is left, and every summary names the kernel sources it was taken on."""
     import glob
     for f in glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json")):
         tj = json.load(open(f))
         v = tj.get("valu") or {}
-        if "busy_frac" in v:
-            assert 0.0 < v["busy_frac"] <= 1.0, f
+        if "issue_slots" in v:
+            assert 0.0 < v["issue_slots"] <= 1.0 and 0.0 < v["lane_utilisation"] <= 1.0, f
+            assert "priced_model" not in v and "issue_frac" not in v, f
             assert "source_hash" in tj, f
 
 
