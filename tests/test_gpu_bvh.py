@@ -127,3 +127,90 @@ def test_deferred_mesh_traversal_equals_in_place(gpu):
             os.environ.pop("SPIRA_DEFER_MESH", None)
         else:
             os.environ["SPIRA_DEFER_MESH"] = old
+
+
+def _with_env(gpu, settings, fn):
+    import os
+    old = {k: os.environ.get(k) for k in settings}
+    try:
+        for k, v in settings.items():
+            os.environ[k] = v
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_mesh_pass_organisations_and_session_knobs_agree_bitwise(gpu, prec):
+    """A mesh pass runs as two launches (thin waves park the rays that reach the mesh's box, fat waves traverse them in refilled sessions and
+    carry those paths on).  One launch with the sessions inside it, any number of fat waves, any refill threshold, any leaf size of the tree,
+    sessions that wait for a batch or not: the same pixels and the same segment count, with and without the glass / spectral extension."""
+    s = scenes.scene_s4(level=4)
+    ns, nm, nt = _counts(s)
+    glass = dict(s, materials8=s["materials8"].copy())
+    glass["materials8"][2] = [0.9, 0.95, 1.0, 0, 0, 0, 0.0, -1.45]
+    variants = [{}, {"SPIRA_MESH_TWO_PASS": "0"}, {"SPIRA_MESH_FAT_WAVES_PER_CU": "1"}, {"SPIRA_MESH_FAT_WAVES_PER_CU": "64"}, {"SPIRA_MESH_REFILL": "1"},
+                {"SPIRA_MESH_REFILL": "64"}, {"SPIRA_MESH_MIN_BATCH": "1"}, {"SPIRA_MESH_MIN_BATCH": "100000", "SPIRA_MESH_TWO_PASS": "0"},
+                {"SPIRA_BVH_LEAF": "2"}, {"SPIRA_BVH_LEAF": "3"}, {"SPIRA_BLOCKS_PER_CU": "3"}]
+    for scene, flags in ((s, 0), (glass, gpu.EXT_DIELECTRIC | gpu.EXT_SPECTRAL)):
+        for depth, batch in ((12, 0), (5, 30000)):
+            p = gpu.make_params(240, 135, 6, depth, ns, nm, nt, flags=flags | gpu.KERNEL_WAVEFRONT, seed=21, batch_rays=batch)
+            ref = None
+            for v in variants:
+                def run():
+                    # (a leaf-size change needs a new tree: the context's cache is keyed by the triangle bytes only, so perturb nothing and use a handle)
+                    with gpu.Scene(scene["spheres5"], scene["materials8"], scene["triangles10"], prec) as h:
+                        hdr, _ = h.render(scene["camera12"], p)
+                    return hdr, gpu.counters()["segments"]
+                got = _with_env(gpu, v, run)
+                if ref is None:
+                    ref = got
+                assert np.array_equal(got[0], ref[0]) and got[1] == ref[1], (v, flags, depth)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_bvh_normalised_frame_any_scale_and_position(gpu, oracle, prec):
+    """The tree's boxes live in the mesh's normalised frame (Float32 in both precisions): a mesh scaled by 1e-3 / 1e3 or moved far from the
+    origin — with the camera moved along — must give the linear scan's geometry bit for bit, like the mesh of ordinary size at the origin."""
+    base = scenes.scene_s4(level=3)
+    for scale, shift in ((1.0, (0.0, 0.0, 0.0)), (1e-3, (0.0, 0.0, 0.0)), (1e3, (0.0, 0.0, 0.0)), (1.0, (300.0, -200.0, 150.0)), (0.05, (-40.0, 7.0, 90.0))):
+        if prec == "f32" and (scale != 1.0 and shift != (0.0, 0.0, 0.0)):
+            continue
+        s = dict(base)
+        sh = np.asarray(shift)
+        t = base["triangles10"].copy()
+        for v in range(3):
+            t[:, 3 * v:3 * v + 3] = t[:, 3 * v:3 * v + 3] * scale + sh
+        sp = base["spheres5"].copy()
+        sp[:, :3] = sp[:, :3] * scale + sh
+        sp[:, 3] *= scale
+        cam = np.asarray(base["camera12"], dtype=np.float64).copy()
+        cam[0:3] = cam[0:3] * scale + sh          # origin
+        cam[3:6] = cam[3:6] * scale + sh          # lower-left corner (a point)
+        cam[6:12] *= scale                        # horizontal, vertical (vectors)
+        s.update(triangles10=t, spheres5=sp, camera12=cam)
+        hits = _trace_equal(gpu, oracle, s, prec, n=1200, window=(68, 94, 34, 58))       # (asserts bit-equality path by path)
+        # (at scale 1e-3 the reference's own absolute thresholds — |a| < 1e-8 in the triangle test, t_min = 0.001 — leave no triangle hit: oracle and GPU agree on that too)
+        assert hits > 100 or scale < 0.01, (scale, shift, hits)
+
+
+def test_bvh_far_camera_and_axis_parallel_rays(gpu, oracle):
+    """Rays that start hundreds of mesh sizes away (the Float32 side of a ray starts where it enters the mesh's box) and rays parallel to an
+    axis (1/d clamped) against a mesh of axis-aligned quads: bit-exact against the linear scan."""
+    rng = np.random.default_rng(4)
+    quads = []
+    for k in range(300):                           # axis-aligned little squares at random places: many boxes of zero extent along one axis
+        c = rng.uniform(-1, 1, 3)
+        ax = k % 3
+        u, v = np.roll(np.eye(3), ax, axis=1)[0] * 0.2, np.roll(np.eye(3), ax, axis=1)[1] * 0.2
+        quads.append(list(c) + list(c + u) + list(c + v) + [1.0])
+        quads.append(list(c + u) + list(c + u + v) + list(c + v) + [1.0])
+    s = dict(spheres5=np.zeros((0, 5)), materials8=np.array([[0.8, 0.8, 0.8, 0, 0, 0, 0.5, 0.0]]), triangles10=np.array(quads))
+    from spira_hip import _binding as B
+    for pos, look in (([0.0, 0.0, 500.0], [0.0, 0.0, 0.0]), ([0.0, 0.0, 3.0], [0.0, 0.0, 0.0]), ([250.0, 0.0, 0.0], [0.0, 0.0, 0.0])):
+        s["camera12"] = B.camera_lookat(pos, look, [0.0, 1.0, 0.0], 0.4 if max(map(abs, pos)) > 100 else 40.0, 16.0 / 9.0, 1.0, prec="f64")
+        assert _trace_equal(gpu, oracle, s, "f64", W=161, H=91, n=1500) > 100, pos      # odd sizes: the centre pixel's ray is exactly axis-parallel
