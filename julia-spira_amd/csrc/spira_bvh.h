@@ -22,8 +22,9 @@
 //   0..2   p.xyz      Float32 origin of the node's quantisation grid (normalised frame)
 //   3      ex | ey<<8 | ez<<16 | imask<<24     biased exponents of the grid steps (step = 2^(e-127)); imask bit s: child slot s is a node
 //   4      child_base  slot index of child slot 0 (a block of 8 consecutive slots; slots of absent / leaf children are unused holes)
-//   5      tri_base    first triangle (reordered array) of this node's leaf children
-//   6..7   meta[8]     leaf child s: (unary triangle count 1|3|7) << 5 | offset from tri_base (0..21); node / empty child: 0
+//   5      tri_base    first triangle (reordered array) of this node's leaf children (one triangle per leaf child, in slot order; < 2^24)
+//   6      rank[8]     4 bits per slot: leaf child s holds triangle tri_base + rank_s (its rank among the node's leaf slots); else 0
+//   7      reserved (0)
 //   8..19  qlo_x[8] qlo_y[8] qlo_z[8] qhi_x[8] qhi_y[8] qhi_z[8]   child boxes on the grid, one byte each (an empty child: lo 255, hi 0)
 // Child slots are assigned so that slot index bit k says "on the positive side along axis k" (greedy assignment on centroid
 // offsets): visiting hit children in ascending (slot XOR ray octant) order is approximately front to back.
@@ -42,7 +43,7 @@ namespace spira {
 constexpr uint32_t kBvhMaxTris = 1u << 24;
 constexpr int kBvhStack = 64;                 // traversal stack levels (one entry per 8-wide level at most)
 constexpr uint32_t kBvhNodeDwords = 20;
-constexpr uint32_t kBvhLeafTris = 3;          // triangles per leaf child (3 x 8 = 24 bits of a node's triangle mask)
+constexpr uint32_t kBvhLeafTris = 1;          // triangles per leaf child: its quantised box is the triangle's own (1: 7.8 walk trips per camera ray on config 5; 3: 8.6)
 constexpr int kBvhInvClampExp = 40;           // traversal: |1/d| is clamped to 2^40 (normalised frame: coordinates within ~1)
 
 template <class T> struct HostPack4 { T x, y, z, w; };
@@ -70,7 +71,6 @@ template <class T> struct Bvh8Build {
     struct BNode { double mn[3], mx[3]; int left, right; uint32_t first, count; };   // binary SAH tree; left < 0: leaf over items [first, first+count)
     std::vector<Item> items;
     std::vector<BNode> bn;
-    uint32_t leaf_tris = kBvhLeafTris;
 
     static double area(const double a[3], const double b[3]) {
         double e0 = std::max(0.0, b[0] - a[0]), e1 = std::max(0.0, b[1] - a[1]), e2 = std::max(0.0, b[2] - a[2]);
@@ -90,7 +90,7 @@ template <class T> struct Bvh8Build {
             }
         for (int k = 0; k < 3; ++k) { bn[me].mn[k] = mn[k]; bn[me].mx[k] = mx[k]; }
         bn[me].first = first; bn[me].count = count; bn[me].left = bn[me].right = -1;
-        if (count <= leaf_tris) return me;
+        if (count <= kBvhLeafTris) return me;
         constexpr int NB = 16;
         int best_axis = -1, best_bin = -1;
         double best_cost = std::numeric_limits<double>::infinity();
@@ -144,8 +144,8 @@ template <class T> struct Bvh8Build {
 // Builds the structure over n triangles (caller's triangles10 layout).  Outputs: nodes (kBvhNodeDwords per slot, slot 0 = root),
 // tris (3 packets per triangle, node order), frame.  Returns false if a limit is hit.
 template <class T>
-bool bvh_build(const T *triangles10, uint32_t n, std::vector<uint32_t> &nodes, std::vector<HostPack4<T>> &tris, BvhFrame<T> &frame, uint32_t leaf_tris = kBvhLeafTris) {
-    if (n == 0 || n > kBvhMaxTris || leaf_tris < 1 || leaf_tris > kBvhLeafTris) return false;
+bool bvh_build(const T *triangles10, uint32_t n, std::vector<uint32_t> &nodes, std::vector<HostPack4<T>> &tris, BvhFrame<T> &frame) {
+    if (n == 0 || n > kBvhMaxTris) return false;
     // ---- frame: centre and power-of-two scale from the bounds of all vertices
     double lo[3], hi[3], amax = 0;
     for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<double>::infinity(); hi[k] = -lo[k]; }
@@ -170,7 +170,6 @@ bool bvh_build(const T *triangles10, uint32_t n, std::vector<uint32_t> &nodes, s
     const double amax_n = amax * scale;
     const double pad = sizeof(T) == 4 ? 1e-4 * std::max(1.0, amax_n) : 1e-4 + 1e-9 * amax_n;
     Bvh8Build<T> b;
-    b.leaf_tris = leaf_tris;
     b.items.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         const T *t = triangles10 + 10 * (size_t)i;
@@ -255,8 +254,8 @@ bool bvh_build(const T *triangles10, uint32_t n, std::vector<uint32_t> &nodes, s
             if (e > 120) return false;
             eb[k] = (uint32_t)(e + 127);
         }
-        uint32_t imask = 0, n_int = 0;
-        uint8_t meta[8] = {0}, q[6][8];
+        uint32_t imask = 0, n_int = 0, rank_word = 0;
+        uint8_t q[6][8];
         for (int s = 0; s < 8; ++s) { for (int a = 0; a < 3; ++a) { q[a][s] = 255; q[3 + a][s] = 0; } }
         const uint32_t tri_base = (uint32_t)order.size();
         uint32_t tri_off = 0;
@@ -274,10 +273,10 @@ bool bvh_build(const T *triangles10, uint32_t n, std::vector<uint32_t> &nodes, s
             }
             if (c.left >= 0) { imask |= 1u << s; ++n_int; }
             else {
-                if (c.count < 1 || c.count > kBvhLeafTris) return false;
-                meta[s] = (uint8_t)((((1u << c.count) - 1u) << 5) | tri_off);
-                for (uint32_t i = c.first; i < c.first + c.count; ++i) order.push_back(i);
-                tri_off += c.count;
+                if (c.count != 1) return false;
+                rank_word |= tri_off << (4 * s);
+                order.push_back(c.first);
+                ++tri_off;
             }
         }
         uint32_t child_base = 0;
@@ -298,8 +297,8 @@ bool bvh_build(const T *triangles10, uint32_t n, std::vector<uint32_t> &nodes, s
         w[0] = float_bits(p[0]); w[1] = float_bits(p[1]); w[2] = float_bits(p[2]);
         w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16) | (imask << 24);
         w[4] = child_base; w[5] = tri_base;
-        w[6] = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
-        w[7] = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
+        w[6] = rank_word;
+        w[7] = 0;
         for (int a = 0; a < 6; ++a) {
             w[8 + 2 * a] = q[a][0] | (q[a][1] << 8) | (q[a][2] << 16) | ((uint32_t)q[a][3] << 24);
             w[9 + 2 * a] = q[a][4] | (q[a][5] << 8) | (q[a][6] << 16) | ((uint32_t)q[a][7] << 24);

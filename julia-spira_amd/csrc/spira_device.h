@@ -409,8 +409,8 @@ struct Bvh8Ray {
 };
 template <class T> struct Bvh8Walk {      // one lane's traversal state
     uint32_t G;              // current node group: child_base << 8 | hit children still to visit, bit (slot ^ oct): ascending = front to back
-    uint32_t trimask;        // triangles of the current node still to test (bit j: tri_base + j)
-    uint32_t tri_base;
+    uint32_t tw;             // triangles of the current node still to test: hit leaf slots << 24 | the node's tri_base
+    uint32_t rank;           // the node's leaf ranks (4 bits per slot): the triangle of leaf slot s is tri_base + rank_s
     int sp;
     T t0;                    // ray parameter of (ox, oy, oz)
 };
@@ -440,45 +440,42 @@ __device__ __forceinline__ bool bvh8_enter(const SceneLds<T> &sc, Vec<T> o, Vec<
     return true;
 }
 
-__device__ __forceinline__ float bvh8_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }      // v_cvt_f32_ubyteK
+typedef float F2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ F2 bvh8_bytes(uint32_t w0, uint32_t w1, int k) {      // byte k of both words as floats (v_cvt_f32_ubyteK x 2): children k and k + 4
+    F2 r; r.x = (float)((w0 >> (8 * k)) & 0xFFu); r.y = (float)((w1 >> (8 * k)) & 0xFFu); return r;
+}
 
-// One node: slab tests of its 8 children.  Out: ih = hit child NODES, bit (slot ^ oct); trimask / tri_base = triangles of the hit leaf children.
+// One node: slab tests of its 8 children, two at a time (v_pk_fma_f32).  Out: ih = hit child NODES, bit (slot ^ oct); lh = hit leaf slots.
 __device__ __forceinline__ void bvh8_node(const uint4 w0, const uint4 w1, const uint4 w2, const uint4 w3, const uint4 w4, const Bvh8Ray &r,
-                                          uint32_t &ih, uint32_t &child_base, uint32_t &trimask, uint32_t &tri_base) {
+                                          uint32_t &ih, uint32_t &lh) {
     const float sx = __uint_as_float((w0.w & 0xFFu) << 23), sy = __uint_as_float(((w0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((w0.w >> 16) & 0xFFu) << 23);
     const uint32_t imask = w0.w >> 24;
     const float ax = sx * r.ix, ay = sy * r.iy, az = sz * r.iz;
     const float bx = (__uint_as_float(w0.x) - r.ox) * r.ix, by = (__uint_as_float(w0.y) - r.oy) * r.iy, bz = (__uint_as_float(w0.z) - r.oz) * r.iz;
+    const F2 ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
     // near / far planes per axis by the sign of the direction: lo_x = w2.xy, lo_y = w2.zw, lo_z = w3.xy, hi_x = w3.zw, hi_y = w4.xy, hi_z = w4.zw
     const bool nx = (r.oct & 1u) != 0, ny = (r.oct & 2u) != 0, nz = (r.oct & 4u) != 0;
     const uint32_t nxw[2] = {nx ? w3.z : w2.x, nx ? w3.w : w2.y}, fxw[2] = {nx ? w2.x : w3.z, nx ? w2.y : w3.w};
     const uint32_t nyw[2] = {ny ? w4.x : w2.z, ny ? w4.y : w2.w}, fyw[2] = {ny ? w2.z : w4.x, ny ? w2.w : w4.y};
     const uint32_t nzw[2] = {nz ? w4.z : w3.x, nz ? w4.w : w3.y}, fzw[2] = {nz ? w3.x : w4.z, nz ? w3.y : w4.w};
-    uint32_t hits = 0;
+    uint32_t hlo = 0, hhi = 0;                                        // children 0..3, children 4..7
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int wi = i >> 2, k = i & 3;
-        const float tnx = __builtin_fmaf(bvh8_byte(nxw[wi], k), ax, bx), tfx = __builtin_fmaf(bvh8_byte(fxw[wi], k), ax, bx);
-        const float tny = __builtin_fmaf(bvh8_byte(nyw[wi], k), ay, by), tfy = __builtin_fmaf(bvh8_byte(fyw[wi], k), ay, by);
-        const float tnz = __builtin_fmaf(bvh8_byte(nzw[wi], k), az, bz), tfz = __builtin_fmaf(bvh8_byte(fzw[wi], k), az, bz);
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
-        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, r.best));
-        hits |= (tn <= tf) ? (1u << i) : 0u;
+    for (int k = 3; k >= 0; --k) {
+        const F2 tnx = __builtin_elementwise_fma(bvh8_bytes(nxw[0], nxw[1], k), ax2, bx2), tfx = __builtin_elementwise_fma(bvh8_bytes(fxw[0], fxw[1], k), ax2, bx2);
+        const F2 tny = __builtin_elementwise_fma(bvh8_bytes(nyw[0], nyw[1], k), ay2, by2), tfy = __builtin_elementwise_fma(bvh8_bytes(fyw[0], fyw[1], k), ay2, by2);
+        const F2 tnz = __builtin_elementwise_fma(bvh8_bytes(nzw[0], nzw[1], k), az2, bz2), tfz = __builtin_elementwise_fma(bvh8_bytes(fzw[0], fzw[1], k), az2, bz2);
+        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(tnx.x, tny.x), __builtin_fmaxf(tnz.x, 0.0f)), tf0 = __builtin_fminf(__builtin_fminf(tfx.x, tfy.x), __builtin_fminf(tfz.x, r.best));
+        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(tnx.y, tny.y), __builtin_fmaxf(tnz.y, 0.0f)), tf1 = __builtin_fminf(__builtin_fminf(tfx.y, tfy.y), __builtin_fminf(tfz.y, r.best));
+        hlo = hlo + hlo + ((tn0 <= tf0) ? 1u : 0u);                   // (descending k: child k ends up at bit k)
+        hhi = hhi + hhi + ((tn1 <= tf1) ? 1u : 0u);
     }
-    uint32_t ihs = hits & imask, lh = hits & ~imask;
+    const uint32_t hits = hlo | (hhi << 4);
+    uint32_t ihs = hits & imask;
+    lh = hits & ~imask;
     if (nx) ihs = ((ihs & 0x55u) << 1) | ((ihs >> 1) & 0x55u);       // bit s -> bit s ^ oct
     if (ny) ihs = ((ihs & 0x33u) << 2) | ((ihs >> 2) & 0x33u);
     if (nz) ihs = ((ihs & 0x0Fu) << 4) | (ihs >> 4);
     ih = ihs;
-    child_base = w1.x; tri_base = w1.y;
-    uint32_t tm = 0;
-    while (lh) {                                                      // few bits: the hit leaf children
-        const uint32_t s_ = (uint32_t)__builtin_ctz(lh);
-        lh &= lh - 1u;
-        const uint32_t m = ((s_ & 4u) ? w1.w : w1.z) >> (8u * (s_ & 3u));
-        tm |= ((m >> 5) & 7u) << (m & 31u);
-    }
-    trimask = tm;
 }
 
 // a triangle's three packets out of the words a trip loaded (Float32: 3 x uint4, Float64: 6)
@@ -495,7 +492,7 @@ __device__ __forceinline__ void bvh8_tri_words(const uint4 w0, const uint4 w1, c
 
 // start at the root: a group holding only slot 0 (child_base 0, bit 0 ^ oct: slot = bit ^ oct = 0)
 template <class T> __device__ __forceinline__ void bvh8_begin(Bvh8Walk<T> &w, const Bvh8Ray &r, T t0) {
-    w.G = 1u << r.oct; w.trimask = 0; w.tri_base = 0; w.sp = 0; w.t0 = t0;
+    w.G = 1u << r.oct; w.tw = 0; w.rank = 0; w.sp = 0; w.t0 = t0;
 }
 
 // One trip of a lane's walk = ONE memory round trip: a lane with triangles pending tests the next one (render precision, caller's
@@ -507,12 +504,13 @@ template <class T, int KL>
 __device__ __forceinline__ bool bvh8_step(const SceneLds<T> &sc, Bvh8Walk<T> &w, Bvh8Ray &r, Vec<T> o, Vec<T> d, T t_min, int base, T &closest, int &prim, uint32_t &slot,
                                           uint32_t *lds_stack, uint32_t *stack, uint32_t lane) {
     constexpr bool kWide = sizeof(T) == 8;
-    const bool is_tri = w.trimask != 0;
+    const bool is_tri = (w.tw >> 24) != 0;
     const uint4 *ptr;
     uint32_t ti = 0;
     if (is_tri) {
-        ti = w.tri_base + (uint32_t)__builtin_ctz(w.trimask);
-        w.trimask &= w.trimask - 1u;
+        const uint32_t s_ = (uint32_t)__builtin_ctz(w.tw >> 24);           // the next hit leaf slot; its triangle: tri_base + rank of the slot
+        ti = (w.tw & 0x00FFFFFFu) + ((w.rank >> (4u * s_)) & 15u);
+        w.tw &= ~(0x01000000u << s_);
         ptr = reinterpret_cast<const uint4 *>(sc.bvh_tris + 3 * (size_t)ti);
     } else {
         const uint32_t pos = (uint32_t)__builtin_ctz(w.G);                 // (the low byte is never empty here)
@@ -529,9 +527,9 @@ __device__ __forceinline__ bool bvh8_step(const SceneLds<T> &sc, Bvh8Walk<T> &w,
     // would be sunk behind the other arm's arithmetic — a second round trip.  The empty asm pins all of them ahead of both arms.
     uint4 w0 = ptr[0], w1 = ptr[1], w2 = ptr[2], w3 = ptr[3], w4 = ptr[4], w5 = make_uint4(0, 0, 0, 0);
     if (kWide) w5 = ptr[5];
-    asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(w0.z), "+v"(w0.w), "+v"(w1.x), "+v"(w1.y), "+v"(w1.z), "+v"(w1.w), "+v"(w2.x), "+v"(w2.y), "+v"(w2.z), "+v"(w2.w));
-    asm volatile("" : "+v"(w3.x), "+v"(w3.y), "+v"(w3.z), "+v"(w3.w), "+v"(w4.x), "+v"(w4.y), "+v"(w4.z), "+v"(w4.w));
-    if (kWide) asm volatile("" : "+v"(w5.x), "+v"(w5.y), "+v"(w5.z), "+v"(w5.w));
+    asm volatile("" :: "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w), "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(w2.w) : "memory");
+    asm volatile("" :: "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w) : "memory");
+    if (kWide) asm volatile("" :: "v"(w5.x), "v"(w5.y), "v"(w5.z), "v"(w5.w) : "memory");
     if (is_tri) {
         Pack4<T> v0, e1, e2;
         bvh8_tri_words(w0, w1, w2, w3, w4, w5, v0, e1, e2);
@@ -544,11 +542,13 @@ __device__ __forceinline__ bool bvh8_step(const SceneLds<T> &sc, Bvh8Walk<T> &w,
             }
         }
     } else {
-        uint32_t ih, cb;
-        bvh8_node(w0, w1, w2, w3, w4, r, ih, cb, w.trimask, w.tri_base);
-        w.G = (cb << 8) | ih;
+        uint32_t ih, lh;
+        bvh8_node(w0, w1, w2, w3, w4, r, ih, lh);
+        w.G = (w1.x << 8) | ih;
+        w.tw = w1.y | (lh << 24);
+        w.rank = w1.z;
     }
-    if (w.trimask == 0 && !(w.G & 0xFFu)) {
+    if ((w.tw >> 24) == 0 && !(w.G & 0xFFu)) {
         if (w.sp == 0) return false;
         --w.sp;
         w.G = (KL > 0 && w.sp < KL) ? lds_stack[w.sp * 64 + lane] : stack[w.sp - KL];
@@ -1192,7 +1192,9 @@ __device__ unsigned long long g_mesh_dbg[32];        // [16..31]: the same for t
 #define MESH_STAT(...)
 #endif
 
-template <class T, int R, bool BVH, bool EXT, bool SPEC>
+// MODE (mesh scenes, PathArgs::mesh_mode): 0 = one launch with the traversal sessions inside, 1 = first of two launches (parks, never walks: the
+// session code is not compiled in — it cost the first launch 9 % through register allocation alone), 2 = second launch (no camera rays).
+template <class T, int R, bool BVH, bool EXT, bool SPEC, int MODE = 0>
 __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const PathArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
@@ -1220,7 +1222,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
         if (lane == 0) atomicAdd(&a.stats->redone_waves, 1ull);
     }
     Pack4<T> *s_rnd = reinterpret_cast<Pack4<T> *>(lds_raw + scene_lds_bytes<T>(a.scene.n_spheres, a.scene.n_materials, a.scene.n_triangles)) + wave * SUB;
-    const uint32_t mesh_mode = BVH ? a.mesh_mode : 0u;
+    constexpr uint32_t mesh_mode = BVH ? (uint32_t)MODE : 0u;
     const uint32_t kseg = mesh_mode == 2u ? a.resume_k : 1u;
     if (mesh_mode == 2u && wid * kseg >= a.resume_nw) return;    // wave-uniform; no workgroup barrier follows
     const uint32_t region = wid * kseg * a.cap;                  // (a fat wave owns the regions of the k waves it takes over)
@@ -1273,7 +1275,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     MESH_STAT(unsigned long long dbg_t0 = __builtin_readcyclecounter(); unsigned long long dbg_sess = 0, dbg_walk = 0; uint32_t dbg_ns = 0, dbg_ws = 0, dbg_ls = 0, dbg_rf = 0, dbg_rays = 0, dbg_rounds = 0, dbg_ws1 = 0, dbg_ls1 = 0, dbg_h[4] = {0, 0, 0, 0};)
     for (uint32_t round = 0; ; ++round) {
         MESH_STAT(++dbg_rounds;)
-        const bool first = round == 0;
+        const bool first = mesh_mode != 2u && round == 0;
         const RayQueue<T> qin = a.q[(round + 1) & 1], qout = a.q[round & 1];
         const uint32_t *rin = a.qref[(round + 1) & 1];
         uint32_t *rout = a.qref[round & 1];
@@ -1509,7 +1511,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
             Vec<T> o_ = mk<T>(0, 0, 0), d_ = mk<T>(0, 0, 1), beta_ = mk<T>(0, 0, 0);
             T closest = 0; uint32_t q_ = 0, stage_hit = 0, slot = 0; int prim = -1;
             Bvh8Ray ry; ry.ox = ry.oy = ry.oz = 0; ry.ix = ry.iy = ry.iz = 1; ry.oct = 0; ry.best = 0;
-            Bvh8Walk<T> wk; wk.G = 0; wk.trimask = 0; wk.tri_base = 0; wk.sp = 0; wk.t0 = 0;
+            Bvh8Walk<T> wk; wk.G = 0; wk.tw = 0; wk.rank = 0; wk.sp = 0; wk.t0 = 0;
             while (true) {
                 // ---- emit what is finished, refill the free lanes (wave-uniform block)
                 const unsigned long long mh = __ballot(finished && prim >= 0);

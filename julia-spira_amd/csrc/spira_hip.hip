@@ -252,7 +252,7 @@ template <class T> struct HostBvh {
 template <class T>
 int host_bvh_build(const T *triangles10, uint32_t nt, HostBvh<T> &hb) {
     spira::BvhFrame<T> fr{};
-    if (!spira::bvh_build<T>(triangles10, nt, hb.nodes, hb.tris, fr, std::min<uint32_t>(spira::kBvhLeafTris, std::max<uint32_t>(1, env_u32("SPIRA_BVH_LEAF", 1)))))
+    if (!spira::bvh_build<T>(triangles10, nt, hb.nodes, hb.tris, fr))
         return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
     hb.frame[0] = {fr.root_mn[0], fr.root_mn[1], fr.root_mn[2], (T)0}; hb.frame[1] = {fr.root_mx[0], fr.root_mx[1], fr.root_mx[2], (T)0};
     hb.frame[2] = {fr.centre[0], fr.centre[1], fr.centre[2], fr.scale};
@@ -335,32 +335,38 @@ void launch_bounce(int R, dim3 grid, size_t lds, hipStream_t st, const spira::Bo
 // k_path.  `spec`: the speculative-division instantiation first (PathArgs::redo = its per-wave report), then the exact one over the
 // waves it reported (spira_device.h, SpecDiv) — two launches, the second normally a grid of workgroups that return at once.
 // spec == 2 (SPIRA_SPEC_DIV=2, tests): every wave is reported, i.e. the whole pass is rendered twice.
-template <class T>
-int launch_path(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathArgs<T> a, int spec) {
-    const bool bvh = a.scene.n_bvh_tris != 0;
+// MODE: PathArgs::mesh_mode as a template argument (mesh scenes: 0 one launch, 1 the parking launch of two; 2 is launch_path_resume below).
+template <class T, bool BVH, int MODE>
+int launch_path_mode(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathArgs<T> a, int spec) {
     const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
     const dim3 blk(spira::kBlock);
     if (ext) {           // extension instantiations (R = 2 only)
         if (spec) {
             a.redo_only = 0;
-            if (bvh) launch_lds(spira::k_path<T, 2, true, true, true>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, true, true>, grid, blk, lds, st, a);
+            launch_lds(spira::k_path<T, 2, BVH, true, true, MODE>, grid, blk, lds, st, a);
             if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
             a.redo_only = 1;
         } else { a.redo = nullptr; a.redo_only = 0; }
-        if (bvh) launch_lds(spira::k_path<T, 2, true, true, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, true, false>, grid, blk, lds, st, a);
+        launch_lds(spira::k_path<T, 2, BVH, true, false, MODE>, grid, blk, lds, st, a);
     } else if (R == 2) {
         if (spec) {
             a.redo_only = 0;
-            if (bvh) launch_lds(spira::k_path<T, 2, true, false, true>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, false, true>, grid, blk, lds, st, a);
+            launch_lds(spira::k_path<T, 2, BVH, false, true, MODE>, grid, blk, lds, st, a);
             if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
             a.redo_only = 1;
         } else { a.redo = nullptr; a.redo_only = 0; }
-        if (bvh) launch_lds(spira::k_path<T, 2, true, false, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 2, false, false, false>, grid, blk, lds, st, a);
+        launch_lds(spira::k_path<T, 2, BVH, false, false, MODE>, grid, blk, lds, st, a);
     } else {
         a.redo = nullptr; a.redo_only = 0;
-        if (bvh) launch_lds(spira::k_path<T, 1, true, false, false>, grid, blk, lds, st, a); else launch_lds(spira::k_path<T, 1, false, false, false>, grid, blk, lds, st, a);
+        launch_lds(spira::k_path<T, 1, BVH, false, false, MODE>, grid, blk, lds, st, a);
     }
     return 0;
+}
+template <class T>
+int launch_path(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<T> &a, int spec) {
+    if (!a.scene.n_bvh_tris) return launch_path_mode<T, false, 0>(R, grid, lds, st, a, spec);
+    if (a.mesh_mode == 1) return launch_path_mode<T, true, 1>(R, grid, lds, st, a, spec);
+    return launch_path_mode<T, true, 0>(R, grid, lds, st, a, spec);
 }
 
 // the second launch of a mesh pass (PathArgs::mesh_mode 2): the exact instantiation — its waves add to radiance the first launch
@@ -370,9 +376,9 @@ void launch_path_resume(int R, dim3 grid, size_t lds, hipStream_t st, spira::Pat
     const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
     const dim3 blk(spira::kBlock);
     a.redo = nullptr; a.redo_only = 0;
-    if (ext) launch_lds(spira::k_path<T, 2, true, true, false>, grid, blk, lds, st, a);
-    else if (R == 2) launch_lds(spira::k_path<T, 2, true, false, false>, grid, blk, lds, st, a);
-    else launch_lds(spira::k_path<T, 1, true, false, false>, grid, blk, lds, st, a);
+    if (ext) launch_lds(spira::k_path<T, 2, true, true, false, 2>, grid, blk, lds, st, a);
+    else if (R == 2) launch_lds(spira::k_path<T, 2, true, false, false, 2>, grid, blk, lds, st, a);
+    else launch_lds(spira::k_path<T, 1, true, false, false, 2>, grid, blk, lds, st, a);
 }
 
 int profile_events(Ctx &c, size_t need) {

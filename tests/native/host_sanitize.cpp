@@ -104,11 +104,9 @@ static void traverse(const std::vector<uint32_t> &nodes, const std::vector<spira
         uint32_t ih = 0, lh = hits & ~imask;
         for (int sl = 0; sl < 8; ++sl) if (hits & imask & (1u << sl)) ih |= 1u << (sl ^ oct);
         G = (w[4] << 8) | ih;
-        uint32_t tm = 0;
-        for (int sl = 0; sl < 8; ++sl)
-            if (lh & (1u << sl)) { const uint32_t m = (w[6 + (sl >> 2)] >> (8 * (sl & 3))) & 0xFFu; tm |= ((m >> 5) & 7u) << (m & 31u); }
+        uint32_t tm = lh;                               // hit leaf slots; the triangle of slot s: tri_base + rank_s (4 bits per slot)
         while (tm) {
-            const uint32_t i = w[5] + (uint32_t)__builtin_ctz(tm);
+            const uint32_t sl = (uint32_t)__builtin_ctz(tm), i = w[5] + ((w[6] >> (4 * sl)) & 15u);
             tm &= tm - 1u;
             CHECK((size_t)i * 3 + 2 < tris.size());
             const auto &a = tris[3 * (size_t)i], &b = tris[3 * (size_t)i + 1], &c = tris[3 * (size_t)i + 2];

@@ -147,7 +147,7 @@ def _with_env(gpu, settings, fn):
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_mesh_pass_organisations_and_session_knobs_agree_bitwise(gpu, prec):
     """A mesh pass runs as two launches (thin waves park the rays that reach the mesh's box, fat waves traverse them in refilled sessions and
-    carry those paths on).  One launch with the sessions inside it, any number of fat waves, any refill threshold, any leaf size of the tree,
+    carry those paths on).  One launch with the sessions inside it, any number of fat waves, any refill threshold,
     sessions that wait for a batch or not: the same pixels and the same segment count, with and without the glass / spectral extension."""
     s = scenes.scene_s4(level=4)
     ns, nm, nt = _counts(s)
@@ -155,7 +155,7 @@ def test_mesh_pass_organisations_and_session_knobs_agree_bitwise(gpu, prec):
     glass["materials8"][2] = [0.9, 0.95, 1.0, 0, 0, 0, 0.0, -1.45]
     variants = [{}, {"SPIRA_MESH_TWO_PASS": "0"}, {"SPIRA_MESH_FAT_WAVES_PER_CU": "1"}, {"SPIRA_MESH_FAT_WAVES_PER_CU": "64"}, {"SPIRA_MESH_REFILL": "1"},
                 {"SPIRA_MESH_REFILL": "64"}, {"SPIRA_MESH_MIN_BATCH": "1"}, {"SPIRA_MESH_MIN_BATCH": "100000", "SPIRA_MESH_TWO_PASS": "0"},
-                {"SPIRA_BVH_LEAF": "2"}, {"SPIRA_BVH_LEAF": "3"}, {"SPIRA_BLOCKS_PER_CU": "3"}]
+                {"SPIRA_BLOCKS_PER_CU": "3"}]
     for scene, flags in ((s, 0), (glass, gpu.EXT_DIELECTRIC | gpu.EXT_SPECTRAL)):
         for depth, batch in ((12, 0), (5, 30000)):
             p = gpu.make_params(240, 135, 6, depth, ns, nm, nt, flags=flags | gpu.KERNEL_WAVEFRONT, seed=21, batch_rays=batch)
