@@ -574,7 +574,9 @@ __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o,
 // :145-187 (LDS-resident), then the BVH for large meshes.  Returns the object index (spheres first, then
 // triangles in the caller's order) or -1.
 // The LDS-resident part of the scan (spheres, then the small triangle set); `closest` / `prim` come in as "nothing yet" and go out updated.
-template <class T, class P>
+// TRI = false: an instantiation for scenes without LDS-resident triangles (spheres only, or spheres + a BVH mesh) — the triangle scan and
+// the triangle arms of the shading code are not compiled in, which is worth 3 % on S1 in Float64 through register allocation alone.
+template <class T, class P, bool TRI = true>
 __device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, P &pol) {
     closest = (T)INFINITY;                                     // t_max = Inf, :335
     prim = -1;
@@ -609,7 +611,7 @@ __device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> 
             if (ok) { closest = root; prim = (int)s; }         // :137, :252
         }
     }
-    if (sc.n_triangles) {
+    if (TRI && sc.n_triangles) {
         Pack4<T> v0n = sc.tri[0], e1n = sc.tri[1], e2n = sc.tri[2];
 #pragma unroll 2       // as for the spheres: +3 % on S3 in f64, neutral elsewhere
         for (uint32_t i = 0; i < sc.n_triangles; ++i) {
@@ -636,10 +638,10 @@ __device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> 
     ExactDiv exact;
     closest_hit_local<T>(sc, o, d, t_min, closest, prim, exact);
 }
-template <class T, bool BVH, class P>
+template <class T, bool BVH, class P, bool TRI = true>
 __device__ __forceinline__ int closest_hit(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &t_hit, uint32_t &slot, P &pol) {
     T closest; int prim;
-    closest_hit_local<T>(sc, o, d, t_min, closest, prim, pol);
+    closest_hit_local<T, P, TRI>(sc, o, d, t_min, closest, prim, pol);
     slot = 0;
     if (BVH) bvh_closest_hit<T>(sc, o, d, t_min, closest, prim, slot);
     t_hit = closest;
@@ -723,29 +725,29 @@ template <class T, bool EXT> __device__ __forceinline__ Vec<T> sky_term_x(const 
 }
 
 // material index (0-based) of a hit object
-template <class T, bool BVH> __device__ __forceinline__ int material_of(const SceneLds<T> &sc, int prim, uint32_t slot) {
-    if (prim < (int)sc.n_spheres) return sc.smat[prim];
-    if (!BVH || prim < (int)(sc.n_spheres + sc.n_triangles)) return sc.tmat[prim - (int)sc.n_spheres];
+template <class T, bool BVH, bool TRI = true> __device__ __forceinline__ int material_of(const SceneLds<T> &sc, int prim, uint32_t slot) {
+    if ((!TRI && !BVH) || prim < (int)sc.n_spheres) return sc.smat[prim];
+    if (TRI && (!BVH || prim < (int)(sc.n_spheres + sc.n_triangles))) return sc.tmat[prim - (int)sc.n_spheres];
     return (int)Bits<T>::to_u32(sc.bvh_tris[3 * (size_t)slot + 1].w);
 }
 
 // Everything that follows a hit at `pos` (= o + d*t) except the random vector: normal, emitted term, and — when
 // the path scatters — throughput and the pending direction data.  Returns whether the emitted term is non-zero.
-template <class T, bool BVH, bool EXT, class P>
+template <class T, bool BVH, bool EXT, class P, bool TRI = true>
 __device__ __forceinline__ bool shade_hit(const SceneLds<T> &sc, const Vec<T> pos, const Vec<T> d, int prim, uint32_t slot, Vec<T> &beta,
                                           bool scatter, Vec<T> &contrib, Pending<T> &pend, const ExtState<T> *ext, P &pol) {
     Vec<T> n;
-    if (prim < (int)sc.n_spheres) {
+    if ((!TRI && !BVH) || prim < (int)sc.n_spheres) {
         const Pack4<T> c = sc.sph[prim];
         n = normalize(pos - mk<T>(c.x, c.y, c.z), pol);                      // :139
-    } else if (!BVH || prim < (int)(sc.n_spheres + sc.n_triangles)) {
+    } else if (TRI && (!BVH || prim < (int)(sc.n_spheres + sc.n_triangles))) {
         int ti = prim - (int)sc.n_spheres;
         n = mk<T>(sc.tri[3 * ti].w, sc.tri[3 * ti + 1].w, sc.tri[3 * ti + 2].w);        // :105-109, precomputed by stage_scene
     } else {
         const Pack4<T> e1p = sc.bvh_tris[3 * (size_t)slot + 1], e2p = sc.bvh_tris[3 * (size_t)slot + 2];
         n = normalize(cross(mk<T>(e1p.x, e1p.y, e1p.z), mk<T>(e2p.x, e2p.y, e2p.z)));   // :105-109
     }
-    const int mi = material_of<T, BVH>(sc, prim, slot);
+    const int mi = material_of<T, BVH, TRI>(sc, prim, slot);
     const Pack4<T> ma = sc.mat[2 * mi], mb = sc.mat[2 * mi + 1];
     Vec<T> diffuse = mk<T>(ma.x, ma.y, ma.z), emission = mk<T>(mb.x, mb.y, mb.z);
     T specular = ma.w, roughness = mb.w;
@@ -1194,8 +1196,14 @@ __device__ unsigned long long g_mesh_dbg[32];        // [16..31]: the same for t
 
 // MODE (mesh scenes, PathArgs::mesh_mode): 0 = one launch with the traversal sessions inside, 1 = first of two launches (parks, never walks: the
 // session code is not compiled in — it cost the first launch 9 % through register allocation alone), 2 = second launch (no camera rays).
-template <class T, int R, bool BVH, bool EXT, bool SPEC, int MODE = 0>
-__global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const PathArgs<T> a) {
+#ifndef SPIRA_WAVES_B_F32
+#define SPIRA_WAVES_B_F32 SPIRA_WAVES_F32
+#endif
+#ifndef SPIRA_WAVES_B_F64
+#define SPIRA_WAVES_B_F64 SPIRA_WAVES_F64
+#endif
+template <class T, int R, bool BVH, bool EXT, bool SPEC, int MODE = 0, bool TRI = true>
+__global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B_F64 : SPIRA_WAVES_B_F32) : SPIRA_WAVES_PER_SIMD(T)) void k_path(const PathArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
     constexpr bool kRefArray = sizeof(T) == 4;
@@ -1203,7 +1211,8 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t NW = gridDim.x * WPB, wid = blockIdx.x * WPB + wave;
     const RenderConst<T> &rc = a.rc;
-    typename std::conditional<SPEC, SpecDiv, ExactDiv>::type pol;   // how this instantiation divides (see SpecDiv)
+    using Pol = typename std::conditional<SPEC, SpecDiv, ExactDiv>::type;
+    Pol pol;                                                     // how this instantiation divides (see SpecDiv)
     if (!SPEC && a.redo_only) {                                  // the launch behind a speculative one: only what that one reported
         uint32_t any = 0;
         for (uint32_t w = 0; w < WPB; ++w) any |= a.redo[blockIdx.x * WPB + w];
@@ -1307,9 +1316,9 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         T t; uint32_t slot = 0;
                         int prim;
                         if (defer) {
-                            closest_hit_local<T>(sc, o[r], d, (T)0.001, t, prim, pol);                 // :335, spheres and LDS triangles
+                            closest_hit_local<T, Pol, TRI>(sc, o[r], d, (T)0.001, t, prim, pol);       // :335, spheres and LDS triangles
                             parked = mesh_box_hit<T>(sc, o[r], d, t);
-                        } else prim = closest_hit<T, BVH>(sc, o[r], d, (T)0.001, t, slot, pol);     // :335
+                        } else prim = closest_hit<T, BVH, Pol, TRI>(sc, o[r], d, (T)0.001, t, slot, pol);     // :335
                         ++n_seg;
                         if (parked) { park_t = t; park_prim = prim; pend[r].v = d; }          // parked below, in uniform control flow
                         else if (prim < 0) {                      // the camera ray leaves the scene: sky, :365-366
@@ -1365,7 +1374,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                             if (rc.flags & kExtSpectral) (void)ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]);
                         }
                         Vec<T> contrib;
-                        const bool has_contrib = shade_hit<T, BVH, EXT>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r], &ex[r], pol);
+                        const bool has_contrib = shade_hit<T, BVH, EXT, Pol, TRI>(sc, o[r], d, prim, slot, beta[r], scatter, contrib, pend[r], &ex[r], pol);
                         // Path radiance L[q]: while bit 31 of q is clear a term is a plain store (0 + x == x exactly); the
                         // load -> add -> store round trip only remains for paths that met an emitter earlier.
                         if (has_contrib) {
@@ -1444,9 +1453,9 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path(const 
                         T t; uint32_t slot = 0;
                         int prim;
                         if (defer) {
-                            closest_hit_local<T>(sc, o[r], nd, (T)0.001, t, prim, pol);             // :335 of the next level, LDS part
+                            closest_hit_local<T, Pol, TRI>(sc, o[r], nd, (T)0.001, t, prim, pol);   // :335 of the next level, LDS part
                             parked3 = mesh_box_hit<T>(sc, o[r], nd, t);
-                        } else prim = closest_hit<T, BVH>(sc, o[r], nd, (T)0.001, t, slot, pol); // :335 of the next level
+                        } else prim = closest_hit<T, BVH, Pol, TRI>(sc, o[r], nd, (T)0.001, t, slot, pol); // :335 of the next level
                         ++n_seg;
                         if (parked3) { park_t3 = t; park_prim3 = prim; pend[r].v = nd; }
                         else if (prim < 0) {                          // the path leaves the scene: its last term, :365-366

@@ -336,9 +336,11 @@ void launch_bounce(int R, dim3 grid, size_t lds, hipStream_t st, const spira::Bo
 // waves it reported (spira_device.h, SpecDiv) — two launches, the second normally a grid of workgroups that return at once.
 // spec == 2 (SPIRA_SPEC_DIV=2, tests): every wave is reported, i.e. the whole pass is rendered twice.
 // MODE: PathArgs::mesh_mode as a template argument (mesh scenes: 0 one launch, 1 the parking launch of two; 2 is launch_path_resume below).
+// TRI = false: the scene holds no LDS-resident triangles (spheres only, or spheres + a BVH mesh): instantiations without the triangle scan
 template <class T, bool BVH, int MODE>
 int launch_path_mode(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathArgs<T> a, int spec) {
     const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
+    const bool tri = a.scene.n_triangles != 0;
     const dim3 blk(spira::kBlock);
     if (ext) {           // extension instantiations (R = 2 only)
         if (spec) {
@@ -351,11 +353,13 @@ int launch_path_mode(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathAr
     } else if (R == 2) {
         if (spec) {
             a.redo_only = 0;
-            launch_lds(spira::k_path<T, 2, BVH, false, true, MODE>, grid, blk, lds, st, a);
+            if (tri) launch_lds(spira::k_path<T, 2, BVH, false, true, MODE, true>, grid, blk, lds, st, a);
+            else launch_lds(spira::k_path<T, 2, BVH, false, true, MODE, false>, grid, blk, lds, st, a);
             if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
             a.redo_only = 1;
         } else { a.redo = nullptr; a.redo_only = 0; }
-        launch_lds(spira::k_path<T, 2, BVH, false, false, MODE>, grid, blk, lds, st, a);
+        if (tri) launch_lds(spira::k_path<T, 2, BVH, false, false, MODE, true>, grid, blk, lds, st, a);
+        else launch_lds(spira::k_path<T, 2, BVH, false, false, MODE, false>, grid, blk, lds, st, a);
     } else {
         a.redo = nullptr; a.redo_only = 0;
         launch_lds(spira::k_path<T, 1, BVH, false, false, MODE>, grid, blk, lds, st, a);
@@ -377,7 +381,8 @@ void launch_path_resume(int R, dim3 grid, size_t lds, hipStream_t st, spira::Pat
     const dim3 blk(spira::kBlock);
     a.redo = nullptr; a.redo_only = 0;
     if (ext) launch_lds(spira::k_path<T, 2, true, true, false, 2>, grid, blk, lds, st, a);
-    else if (R == 2) launch_lds(spira::k_path<T, 2, true, false, false, 2>, grid, blk, lds, st, a);
+    else if (R == 2 && a.scene.n_triangles) launch_lds(spira::k_path<T, 2, true, false, false, 2, true>, grid, blk, lds, st, a);
+    else if (R == 2) launch_lds(spira::k_path<T, 2, true, false, false, 2, false>, grid, blk, lds, st, a);
     else launch_lds(spira::k_path<T, 1, true, false, false, 2>, grid, blk, lds, st, a);
 }
 
