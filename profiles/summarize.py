@@ -32,6 +32,15 @@ def short(name):
     return n.split("(")[0][:60]
 
 
+def is_spec(name):
+    """k_path<T, R, BVH, EXT, SPEC, MODE, TRI>: is this the speculative-division instantiation (the first launch of a pass)?"""
+    n = short(name)
+    if not n.startswith("k_path<"):
+        return False
+    args = [a.strip() for a in n[n.index("<") + 1:n.rindex(">")].split(",")]
+    return len(args) >= 5 and args[4] == "true"
+
+
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     lines = ["# rocprofv3 summary: %s" % os.path.basename(src.rstrip("/")), ""]
@@ -55,7 +64,7 @@ def main():
                 cnt_b += int(r["Calls"])
                 if "k_path" in r["Name"]:
                     path_calls.append(int(r["Calls"]))
-                    if short(r["Name"]).endswith(", true>"):
+                    if is_spec(r["Name"]):
                         spec_calls += int(r["Calls"])
         if path_calls:
             # one k_path "launch" (= one pass) is the speculative-division instantiation <..., true>, the exact one <..., false> behind it, which
@@ -72,7 +81,7 @@ def main():
         had_spec = False
         for r in rows:
             us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-            spec = short(r["Kernel_Name"]).endswith(", true>")
+            spec = is_spec(r["Kernel_Name"])
             if d and not spec and had_spec:
                 d[-1] += us                   # the exact launches behind a speculative one belong to its pass (follow-up; mesh scenes: the fat waves)
             else:
@@ -142,7 +151,7 @@ def main():
         ks = [k for k in agg if k.startswith(dom)]
         # launches: k_bounce instantiations are launches of their own; the k_path instantiations of one run are the speculative launch and
         # its exact follow-up, together one launch
-        spec_ks = [k for k in ks if k.endswith(", true>")]
+        spec_ks = [k for k in ks if is_spec(k)]
         launches_of = ((lambda name: sum(calls[k].get(name, 0) for k in spec_ks) if spec_ks else max([calls[k].get(name, 0) for k in ks] or [0]))
                        if dom == "k_path" else (lambda name: sum(calls[k].get(name, 0) for k in ks)))
         nl = launches_of("FETCH_SIZE")

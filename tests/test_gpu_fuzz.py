@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(rng):
-    kind = rng.choice(["s1", "s2", "s3", "soup_lds", "soup_bvh", "blob"])
+    kinds = os.environ.get("SPIRA_FUZZ_KINDS", "s1,s2,s3,soup_lds,soup_bvh,blob").split(",")      # (one-off campaigns may narrow the scene kinds, e.g. to the BVH ones)
+    kind = rng.choice(kinds)
     if kind == "s1":
         s = scenes.scene_s1()
     elif kind == "s2":
