@@ -74,3 +74,22 @@ def test_config5_full_size_mesh_properties(gpu):
     slab, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=scenes.seed_for(5), row0=400, rows=96), "f32")
     assert np.array_equal(slab, wf[:, 400:496])
     assert np.isfinite(wf).all() and wf.min() >= 0 and nt > 80000 and W * H * spp < seg <= W * H * spp * depth
+
+
+def test_mesh_scene_beyond_128_segments_and_tiny_meshes(gpu, oracle):
+    """max_depth > 128: packets cannot carry their own stage any more, so a mesh scene walks the tree in place (no parking, no second launch);
+    and the smallest meshes that go through the BVH (33 triangles: a root node with leaf children only).  Both against the oracle's linear scan."""
+    s = scenes.scene_s4(level=2)                # 320 triangles
+    ns, nm, nt = _counts(s)
+    for depth in (129, 200):
+        hdr, _ = gpu.render(*_args(s), gpu.make_params(64, 36, 2, depth, ns, nm, nt, seed=6), "f64")
+        ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(64, 36, 2, depth, ns, nm, nt, seed=6), "f64")
+        assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg, depth
+    rng = np.random.default_rng(12)
+    from test_gpu_parity import random_scene
+    for n_tri in (33, 34, 40, 41, 64, 65):
+        t = random_scene(rng, 2, n_tri)
+        ns, nm, nt = _counts(t)
+        hdr, _ = gpu.render(*_args(t), gpu.make_params(80, 45, 3, 5, ns, nm, nt, seed=9), "f32")
+        ohdr, _, oseg = oracle.render(*_args(t), oracle.make_params(80, 45, 3, 5, ns, nm, nt, seed=9), "f32")
+        assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg, n_tri
