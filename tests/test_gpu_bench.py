@@ -1,0 +1,51 @@
+"""GPU (MI355X): bench.py itself at a reduced size — the line the driver keeps carries every key the contract and VERDICT r2 item 2 name, the
+figures are consistent with each other, and PMC figures are attached only when they were measured on the kernel sources of the run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"] + list(args),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_default_line_has_the_contract_keys_and_is_consistent():
+    d = _bench()                                         # the default workload: 1080p, spp 64, depth 8, Float64 (a few seconds on the device)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "end_to_end", "configs", "kernel_source_hash"):
+        assert k in d, k
+    assert d["metric"] == "Msamples/sec at 1920x1080 spp=64 depth=8; fraction of HBM roofline" and d["unit"] == "Msamples/s" and d["dtype"] == "f64"
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
+    assert r["avg_launch_ms"] * r["launches"] <= d["ms_per_step"] * 1.02          # the kernel fits inside the step it was timed in
+    assert abs(d["value"] - d["config"]["samples_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    if r["traffic"] is None:                              # PMC figures of other kernel sources never reach the line
+        assert r["traffic_stale"] in (True, False) and r["valu"] is None
+    else:
+        assert r["traffic_stale"] is False and r["traffic_source"].startswith("profiles/traffic_") and 0 < r["valu"]["issue_slots"] <= 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["end_to_end"]["ms"] > d["ms_per_step"] * 0.5 and d["end_to_end"]["d2h_bytes"] == 3 * 1920 * 1080 * 8
+    for cname, scene, spp, depth in (("c4", "scene s3", 256, 8), ("c5", "scene s4", 64, 12)):
+        e = d["configs"][cname]
+        assert scene in e["workload"] and "spp=%d depth=%d" % (spp, depth) in e["metric"]
+        for pr in ("f64", "f32"):
+            assert e[pr]["value"] > 0 and e[pr]["roofline"]["launches"] == spp // 64 and e[pr]["roofline"]["frac"] > 0
+
+
+def test_config_c5_is_labelled_depth_12():
+    d = _bench("--config", "c5", "--prec", "f32", "--no-extras", "--no-cpu-baseline", "--no-alt-precision")
+    assert "depth=12" in d["metric"] and d["config"]["max_depth"] == 12 and d["config"]["scene"] == "s4" and d["dtype"] == "f32"
+    assert d["roofline"]["segments_per_sample"] > 1.0
