@@ -1135,7 +1135,8 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_bounce(cons
 }
 
 // ====================================================================== the persistent wave-autonomous path kernel
-// One launch per pass.  Differences from k_bounce (kept as SPIRA_KERNEL_BOUNCE, the round-1 organisation):
+// One launch per pass (mesh scenes: two — thin waves that park the rays reaching the mesh's box, then fat waves that walk them; see
+// PathArgs::mesh_mode).  Differences from k_bounce (kept as SPIRA_KERNEL_BOUNCE, the round-1 organisation):
 //   * the queues hold HITS, not rays: the intersection of segment k+1 runs at the END of stage k, right after the new
 //     direction is known, so a ray that leaves the scene adds its sky term and never touches memory; what is queued is
 //     {hit point, incoming direction, throughput, path index, hit reference}.  Every lane that enters the shading code of a
@@ -1161,7 +1162,7 @@ template <class T> struct PathArgs {
     uint32_t n_first;                // number of paths in this pass
     uint32_t dense_pct;              // dense continuation threshold in % (0 = always go through the queue)
     Pack4<T> *mesh_list;             // BVH scenes: per wave `cap` entries of 3 packets — rays that reach the mesh's bounding box wait here
-                                     // for the end of the round and are traversed as dense batches of 64 (NULL = traverse in place)
+                                     // for a traversal session (this wave's, or the fat wave's that takes the list over); NULL = traverse in place
     uint32_t mesh_min_batch;         // parked rays wait (over several rounds if need be) until the wave holds this many — or has nothing else to do
     uint32_t refill_free;            // a traversal session hands new rays to the free lanes once this many lanes are free
     // Mesh scenes run a pass as TWO launches (mesh_mode 1 then 2; 0 = one launch, sessions inside it).  Late in a pass a wave of the
@@ -1246,8 +1247,8 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
     const uint32_t dense_pct = mixed ? a.dense_pct : 0u;
     // Deferred mesh traversal (BVH scenes, max_depth <= 128): a ray that reaches the mesh's bounding box is not traversed where it
     // stands — a few lanes of every wave would walk the tree in global memory while the others wait — but parked on the wave's
-    // mesh list and traversed at the end of the round in dense batches of 64; a hit then enters the out queue as a packet of its
-    // own stage.  (On the 81 920-triangle scene of config 5 the in-place traversal was 70 % of the frame time.)
+    // mesh list; sessions (below) walk the parked rays with all 64 lanes, refilled as rays finish; a hit then enters the out queue as a
+    // packet of its own stage.  (On the 81 920-triangle scene of config 5 the in-place traversal was 70 % of the frame time.)
     const bool defer = BVH && mixed && a.mesh_list != nullptr;
     Pack4<T> *mlist = a.mesh_list + 3 * (size_t)region;
     uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0;

@@ -3,9 +3,10 @@
 //
 // Replaces the host loops of render_hybrid_gpu (src/spira-metal-optimized.jl:1228-1343): the
 // reference launches >= spp*(1 + max_depth*(12*n_spheres + 4)) synchronous kernels with host
-// round trips per depth; here one pass = max_depth bounce kernels + 1 resolve
-// kernel, fully asynchronous on one HIP stream, the live-ray counts staying on the device (one
-// word per wave), and a pass carries `slots` samples of every pixel of the tile at once.
+// round trips per depth; here one pass = one launch of the persistent path kernel
+// (mesh scenes: a parking launch + a fat-wave launch; SPIRA_KERNEL_BOUNCE: max_depth bounce kernels)
+// + 1 resolve kernel, fully asynchronous on one HIP stream, the live-ray counts staying on the
+// device, and a pass carries `slots` samples of every pixel of the tile at once.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types and prototypes only: librccl is opened at run time (dlopen), never linked
 #include <dlfcn.h>
@@ -516,7 +517,10 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     // ---- workspaces (cached per device, grown on demand; sized for 288 GB HBM: no chunking of a pass)
     using P4 = spira::Pack4<T>;
     using P2 = spira::Pack2<T>;
-    if (!mega && p->max_depth > 1)
+    // (max_depth == 1 needs no queue — except on a mesh scene of the persistent organisation: a parked camera ray's hit comes back from its
+    //  traversal session as a packet.  The condition used to be max_depth > 1 alone: a depth-1 mesh render wrote into whatever queues an earlier,
+    //  possibly smaller call had left — found by the fuzz campaign of seed 4041, case 17, as an abort of the process.)
+    if (!mega && (p->max_depth > 1 || (persistent && nt_scene > SPIRA_LDS_TRIANGLES)))
         for (int i = 0; i < 2; ++i) {
             if (int rc = c.qA[i].ensure(q_rays * sizeof(P4))) return rc;
             if (int rc = c.qB[i].ensure(q_rays * sizeof(P4))) return rc;

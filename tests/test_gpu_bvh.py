@@ -104,8 +104,8 @@ def test_config5_full_size_tiling_and_bunny_sized_mesh(gpu):
 
 
 def test_deferred_mesh_traversal_equals_in_place(gpu):
-    """k_path parks rays that reach the mesh's bounding box and traverses them as dense batches at the end of the round (a parked camera
-    ray is shaded one round later; packets carry their own stage).  SPIRA_DEFER_MESH=0 traverses in place: same pixels, same segments —
+    """k_path parks rays that reach the mesh's bounding box and walks them in sessions (a parked ray is shaded a round or more later; packets
+    carry their own stage).  SPIRA_DEFER_MESH=0 traverses in place: same pixels, same segments —
     with glass (extension) and without, depth 1 .. 12."""
     import os
     s = scenes.scene_s4(level=4)
@@ -214,3 +214,16 @@ def test_bvh_far_camera_and_axis_parallel_rays(gpu, oracle):
     for pos, look in (([0.0, 0.0, 500.0], [0.0, 0.0, 0.0]), ([0.0, 0.0, 3.0], [0.0, 0.0, 0.0]), ([250.0, 0.0, 0.0], [0.0, 0.0, 0.0])):
         s["camera12"] = B.camera_lookat(pos, look, [0.0, 1.0, 0.0], 0.4 if max(map(abs, pos)) > 100 else 40.0, 16.0 / 9.0, 1.0, prec="f64")
         assert _trace_equal(gpu, oracle, s, "f64", W=161, H=91, n=1500) > 100, pos      # odd sizes: the centre pixel's ray is exactly axis-parallel
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_depth_one_mesh_render_allocates_its_own_queues(gpu, oracle, prec):
+    """max_depth = 1 on a mesh scene still sends the parked camera rays' hits through the hit queue.  With the device's workspaces freed first
+    (spira_shutdown) the call must size the queues itself — it used to rely on what earlier calls had left (fuzz seed 4041, case 17: a depth-1
+    render larger than every earlier one of its precision aborted the process)."""
+    s = scenes.scene_s4(level=2)
+    ns, nm, nt = _counts(s)
+    gpu.lib().spira_shutdown()
+    hdr, _ = gpu.render(*_args(s), gpu.make_params(62, 52, 7, 1, ns, nm, nt, flags=gpu.POST_NONE, seed=766849796527), prec)
+    ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(62, 52, 7, 1, ns, nm, nt, flags=gpu.POST_NONE, seed=766849796527), prec)
+    assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg

@@ -61,6 +61,9 @@ def test_fuzz_against_oracle(gpu, oracle):
             if tile["rows"] == 0:
                 tile = {}
         flags = sem | kflag | ext | gpu.POST_NONE
+        if os.environ.get("SPIRA_FUZZ_LOG"):      # one line per case BEFORE it runs (flushed): which case a crash of the process belongs to
+            with open(os.environ["SPIRA_FUZZ_LOG"], "a") as fh:
+                fh.write("%d %s ns=%d nm=%d nt=%d %dx%d spp=%d depth=%d %s flags=%#x seed=%d batch=%d tile=%s\n" % (it, kind, ns, nm, nt, W, H, spp, depth, prec, flags, seed, batch, tile))
         hdr, _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, flags=flags, seed=seed, batch_rays=batch, **tile), prec)
         po = oracle.make_params(W, H, spp, depth, ns, nm, nt, flags=flags, seed=seed, **tile)
         if sem == 0:
