@@ -61,6 +61,8 @@ def test_fuzz_against_oracle(gpu, oracle):
             if tile["rows"] == 0:
                 tile = {}
         flags = sem | kflag | ext | gpu.POST_NONE
+        if os.environ.get("SPIRA_FUZZ_FRESH"):    # free the device's cached workspaces first: every case must size what it uses itself
+            gpu.lib().spira_shutdown()
         if os.environ.get("SPIRA_FUZZ_LOG"):      # one line per case BEFORE it runs (flushed): which case a crash of the process belongs to
             with open(os.environ["SPIRA_FUZZ_LOG"], "a") as fh:
                 fh.write("%d %s ns=%d nm=%d nt=%d %dx%d spp=%d depth=%d %s flags=%#x seed=%d batch=%d tile=%s\n" % (it, kind, ns, nm, nt, W, H, spp, depth, prec, flags, seed, batch, tile))
