@@ -44,9 +44,11 @@ CONFIGS = {   # BASELINE.json configs[2..4]: scene, spp, depth, spp is per GPU (
 def algorithmic_bytes(c, prec_bytes, kernel):
     """HBM bytes the wavefront formulation must move (DESIGN.md "Roofline"), from device counters: every queued packet is
     written once and read once, a radiance term is a 3-value store, or a read-modify-write (2 x 3 values) when the path
-    already holds radiance.  Packet: 10 values (+ a 4-byte hit reference in the Float32 hit queues of k_path)."""
+    already holds radiance.  Packet: 10 values (+ a 4-byte hit reference in the Float32 hit queues of k_path).  Mesh scenes: a ray that
+    reaches the mesh's box waits on its wave's mesh list for a traversal session — an entry of 12 values, written once and read once."""
     packet = 10 * prec_bytes + (4 if (kernel == "wavefront" and prec_bytes == 4) else 0)
-    return 2 * packet * c["rays_enqueued"] + (3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes
+    return (2 * packet * c["rays_enqueued"] + 2 * 12 * prec_bytes * c.get("rays_parked", 0)
+            + (3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes)
 
 
 KERNEL_SOURCES = ("spira_device.h", "spira_hip.hip", "spira_bvh.h")
@@ -96,6 +98,7 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape, source_hash=None)
            "bytes_per_launch": round(nbytes / launches), "avg_launch_ms": round(kms / launches, 5), "launches": launches,
            "kernel_ms_per_step": round(kms, 4), "bytes_per_sample": round(nbytes / c["samples"], 2),
            "segments_per_sample": round(c["segments"] / c["samples"], 4), "packets_per_sample": round(c["rays_enqueued"] / c["samples"], 4),
+           "parked_per_sample": round(c.get("rays_parked", 0) / c["samples"], 4),
            "kernel_share_of_step": round(kms / max(c["kernel_ms"], 1e-9), 4),
            # k_path: the speculative-division launch + the exact follow-up over the waves it reported; both inside avg_launch_ms
            "waves_rendered_again": int(c.get("redone_waves", 0)), "valu": None}

@@ -156,6 +156,7 @@ typedef struct spira_counters {
     double   bounce_kernel_ms;   /* device time spent in the dominant (bounce) kernel      */
     uint64_t bounce_launches;    /* launches of that kernel                                 */
     uint64_t redone_waves;       /* waves whose pass was rendered a second time with the compiler's division (speculative division) */
+    uint64_t rays_parked;        /* mesh scenes: rays written to (and read back from) a wave's mesh list: 3 x 16/32 bytes each way */
 } spira_counters;
 
 /* ---- library / device ---- */

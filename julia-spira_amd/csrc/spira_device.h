@@ -525,11 +525,24 @@ __device__ __forceinline__ bool bvh8_step(const SceneLds<T> &sc, Bvh8Walk<T> &w,
     // Every lane loads the same number of words (a node is 5 x 16 bytes, a triangle 3 in Float32 and 6 in Float64; the arrays are padded
     // by one record): a wave-instruction costs the memory pipeline the same whichever lanes take part, and loads under a condition
     // would be sunk behind the other arm's arithmetic — a second round trip.  The empty asm pins all of them ahead of both arms.
-    uint4 w0 = ptr[0], w1 = ptr[1], w2 = ptr[2], w3 = ptr[3], w4 = ptr[4], w5 = make_uint4(0, 0, 0, 0);
-    if (kWide) w5 = ptr[5];
-    asm volatile("" :: "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w), "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(w2.w) : "memory");
-    asm volatile("" :: "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w) : "memory");
-    if (kWide) asm volatile("" :: "v"(w5.x), "v"(w5.y), "v"(w5.z), "v"(w5.w) : "memory");
+    uint4 w0, w1, w2, w3, w4, w5 = make_uint4(0, 0, 0, 0);
+    if constexpr (kWide) {
+        // Float64: written out as the six aligned 16-byte loads they are.  Left to itself the compiler regroups the words by their later use
+        // into loads at odd offsets (dwordx4 at +4, dwordx2 at +0, dwordx3 at +68 ...): -2.5 % on config 5.  (In Float32 its grouping is the
+        // faster one by 5 %: register allocation.)
+        typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+        U4 q0, q1, q2, q3, q4, q5;
+        asm volatile("global_load_dwordx4 %0, %6, off\n\tglobal_load_dwordx4 %1, %6, off offset:16\n\tglobal_load_dwordx4 %2, %6, off offset:32\n\t"
+                     "global_load_dwordx4 %3, %6, off offset:48\n\tglobal_load_dwordx4 %4, %6, off offset:64\n\tglobal_load_dwordx4 %5, %6, off offset:80\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5) : "v"(ptr) : "memory");
+        w0 = make_uint4(q0.x, q0.y, q0.z, q0.w); w1 = make_uint4(q1.x, q1.y, q1.z, q1.w); w2 = make_uint4(q2.x, q2.y, q2.z, q2.w);
+        w3 = make_uint4(q3.x, q3.y, q3.z, q3.w); w4 = make_uint4(q4.x, q4.y, q4.z, q4.w); w5 = make_uint4(q5.x, q5.y, q5.z, q5.w);
+    } else {
+        w0 = ptr[0]; w1 = ptr[1]; w2 = ptr[2]; w3 = ptr[3]; w4 = ptr[4];
+        asm volatile("" :: "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w), "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(w2.w) : "memory");
+        asm volatile("" :: "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w), "v"(w4.x), "v"(w4.y), "v"(w4.z), "v"(w4.w) : "memory");
+    }
     if (is_tri) {
         Pack4<T> v0, e1, e2;
         bvh8_tri_words(w0, w1, w2, w3, w4, w5, v0, e1, e2);
@@ -924,7 +937,7 @@ __device__ __forceinline__ void path_of(const RenderConst<T> &rc, uint32_t q, ui
 template <class T> struct RayQueue { Pack4<T> *A; Pack4<T> *B; Pack2<T> *C; };
 
 struct Stats {                       // device-side counters (one per context)
-    unsigned long long segments, rays_enqueued, radiance_rmw, radiance_store, redone_waves;
+    unsigned long long segments, rays_enqueued, radiance_rmw, radiance_store, redone_waves, rays_parked;
 };
 
 template <class T> struct BounceArgs {
@@ -1251,7 +1264,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
     // packet of its own stage.  (On the 81 920-triangle scene of config 5 the in-place traversal was 70 % of the frame time.)
     const bool defer = BVH && mixed && a.mesh_list != nullptr;
     Pack4<T> *mlist = a.mesh_list + 3 * (size_t)region;
-    uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0;
+    uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0, n_park = 0;   // (n_park: entries written to the mesh list, wave-uniform)
     uint32_t n_in = 0;                                           // packets waiting in this wave's region (rounds >= 1)
     const uint32_t n_sub_first = (a.n_first + SUB - 1) / SUB;
 
@@ -1349,7 +1362,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                 if (defer && first) {                             // camera rays that reach the mesh's box: onto the mesh list (stage of the hit: 0)
                     const unsigned long long mp = __ballot(parked);
                     if (parked) park(mfill + __popcll(mp & lt_mask), o[r], pend[r].v, beta[r], park_t, q[r], park_prim, 0u);
-                    mfill += (uint32_t)__popcll(mp);
+                    mfill += (uint32_t)__popcll(mp); n_park += (uint32_t)__popcll(mp);
                 }
             }
             // ---------------- stages on these rays; normally ONE trip, more while the hits stay dense
@@ -1477,7 +1490,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                     if (defer) {                                  // rays that reach the mesh's box wait for the end of the round
                         const unsigned long long mp = __ballot(parked3);
                         if (parked3) park(mfill + __popcll(mp & lt_mask), o[r], pend[r].v, beta[r], park_t3, q[r], park_prim3, stg[r] + 1u);
-                        mfill += (uint32_t)__popcll(mp);
+                        mfill += (uint32_t)__popcll(mp); n_park += (uint32_t)__popcll(mp);
                     }
                     valid[r] = hit;
                     n_hit += (uint32_t)__popcll(__ballot(hit));
@@ -1620,6 +1633,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
             if (mesh_mode == 1u) a.mesh_count[wid] = mfill;
         }
         if (SPEC) a.redo[wid] = again ? 1u : 0u;
+        if (BVH && n_park && !again && !(SPEC && a.redo_only == 2u)) atomicAdd(&a.stats->rays_parked, (unsigned long long)n_park);      // (a wave rendered again counts there)
     }
 }
 

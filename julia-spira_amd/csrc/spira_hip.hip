@@ -345,7 +345,7 @@ int launch_path_mode(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathAr
     const dim3 blk(spira::kBlock);
     if (ext) {           // extension instantiations (R = 2 only)
         if (spec) {
-            a.redo_only = 0;
+            a.redo_only = spec == 2 ? 2 : 0;          // (2: every wave will be rendered again, whatever it reports)
             launch_lds(spira::k_path<T, 2, BVH, true, true, MODE>, grid, blk, lds, st, a);
             if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
             a.redo_only = 1;
@@ -353,7 +353,7 @@ int launch_path_mode(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathAr
         launch_lds(spira::k_path<T, 2, BVH, true, false, MODE>, grid, blk, lds, st, a);
     } else if (R == 2) {
         if (spec) {
-            a.redo_only = 0;
+            a.redo_only = spec == 2 ? 2 : 0;
             if (tri) launch_lds(spira::k_path<T, 2, BVH, false, true, MODE, true>, grid, blk, lds, st, a);
             else launch_lds(spira::k_path<T, 2, BVH, false, true, MODE, false>, grid, blk, lds, st, a);
             if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
@@ -1217,6 +1217,7 @@ int spira_get_counters(spira_counters *out) {
         c.last.radiance_rmw = c.h_stats->radiance_rmw;
         c.last.radiance_stores = c.h_stats->radiance_store;
         c.last.redone_waves = c.h_stats->redone_waves;
+        c.last.rays_parked = c.h_stats->rays_parked;
         double bms = 0;
         for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
             float m = 0;

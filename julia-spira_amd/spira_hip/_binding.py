@@ -51,7 +51,7 @@ class Params(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("rays_enqueued", C.c_uint64),
                 ("radiance_rmw", C.c_uint64), ("radiance_stores", C.c_uint64), ("passes", C.c_uint64), ("launches", C.c_uint64),
-                ("kernel_ms", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64), ("redone_waves", C.c_uint64)]
+                ("kernel_ms", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64), ("redone_waves", C.c_uint64), ("rays_parked", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

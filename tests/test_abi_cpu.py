@@ -27,7 +27,7 @@ def test_exports_match_header(binding):
 
 def test_struct_sizes(binding):
     assert C.sizeof(binding.Params) == 64
-    assert C.sizeof(binding.Counters) == 11 * 8
+    assert C.sizeof(binding.Counters) == 12 * 8
 
 
 def test_library_is_gfx950_only():

@@ -22,6 +22,10 @@ def test_algorithmic_bytes_per_organisation_and_precision():
     assert bench.algorithmic_bytes(c, 8, "wavefront") == 2 * 80 * 400 + (3 * 1000 + 6 * 10) * 8
     assert bench.algorithmic_bytes(c, 4, "wavefront") == 2 * 44 * 400 + (3 * 1000 + 6 * 10) * 4
     assert bench.algorithmic_bytes(c, 4, "bounce") == 2 * 40 * 400 + (3 * 1000 + 6 * 10) * 4
+    # mesh scenes: an entry of a wave's mesh list is 12 values, written once and read once
+    m = _counters(rays_parked=70)
+    assert bench.algorithmic_bytes(m, 8, "wavefront") - bench.algorithmic_bytes(c, 8, "wavefront") == 2 * 96 * 70
+    assert bench.algorithmic_bytes(m, 4, "wavefront") - bench.algorithmic_bytes(c, 4, "wavefront") == 2 * 48 * 70
 
 
 def test_roofline_record_fields_and_bound(tmp_path, monkeypatch):

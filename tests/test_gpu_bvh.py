@@ -165,11 +165,33 @@ def test_mesh_pass_organisations_and_session_knobs_agree_bitwise(gpu, prec):
                     # (a leaf-size change needs a new tree: the context's cache is keyed by the triangle bytes only, so perturb nothing and use a handle)
                     with gpu.Scene(scene["spheres5"], scene["materials8"], scene["triangles10"], prec) as h:
                         hdr, _ = h.render(scene["camera12"], p)
-                    return hdr, gpu.counters()["segments"]
+                    return hdr, gpu.counters()["segments"], gpu.counters()["rays_parked"]
                 got = _with_env(gpu, v, run)
                 if ref is None:
                     ref = got
                 assert np.array_equal(got[0], ref[0]) and got[1] == ref[1], (v, flags, depth)
+                # the rays that reach the mesh's box wait on a list whatever the organisation (the roofline's bytes count them)
+                assert 0 < got[2] <= got[1] and got[2] == ref[2], (v, got[2], ref[2])
+
+
+def test_rays_parked_counter(gpu):
+    """spira_counters.rays_parked: 0 where no ray ever waits on a mesh list (no mesh; traversal in place), the same number with and
+    without the speculative division (a wave rendered again is counted once)."""
+    s1 = scenes.scene_s1()
+    gpu.render(*_args(s1), gpu.make_params(96, 54, 2, 4, *_counts(s1), seed=3), "f32")
+    assert gpu.counters()["rays_parked"] == 0
+    s = scenes.scene_s4(level=3)
+    p = gpu.make_params(200, 120, 4, 8, *_counts(s), flags=gpu.KERNEL_WAVEFRONT, seed=4)
+    seen = {}
+    for env in ({}, {"SPIRA_SPEC_DIV": "0"}, {"SPIRA_SPEC_DIV": "2"}, {"SPIRA_DEFER_MESH": "0"}):
+        for prec in ("f32", "f64"):
+            def run():
+                gpu.render(*_args(s), p, prec)
+                return gpu.counters()["rays_parked"]
+            seen[(tuple(env.items()), prec)] = _with_env(gpu, env, run)
+    for prec in ("f32", "f64"):
+        a, b, c, d = (seen[(tuple(e.items()), prec)] for e in ({}, {"SPIRA_SPEC_DIV": "0"}, {"SPIRA_SPEC_DIV": "2"}, {"SPIRA_DEFER_MESH": "0"}))
+        assert a > 0 and a == b == c and d == 0, (prec, a, b, c, d)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])

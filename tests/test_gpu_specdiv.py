@@ -59,7 +59,7 @@ def test_modes_are_bit_identical(gpu, prec):
                 c = gpu.counters()
             got[mode] = (hdr, c)
         assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][0], got[2][0])
-        for k in ("segments", "rays_enqueued", "radiance_rmw", "radiance_stores"):
+        for k in ("segments", "rays_enqueued", "radiance_rmw", "radiance_stores", "rays_parked"):
             assert got[0][1][k] == got[1][1][k] == got[2][1][k], k
         assert got[0][1]["redone_waves"] == 0
         assert got[1][1]["redone_waves"] == 0          # an ordinary scene: nothing leaves the window (zeros are handled where they occur)
