@@ -48,7 +48,8 @@ def main():
     if os.path.exists(tlog):
         for ln in open(tlog):
             if ln.startswith("{"):
-                lines += ["bench line of the traced run:", "", "```", ln.strip(), "```", ""]
+                lines += ["bench line of the traced run (its `roofline.traffic*` fields look at the summary committed BEFORE this run — the PMC passes below are this "
+                          "run's own and become `profiles/traffic_*.json` for the next one):", "", "```", ln.strip(), "```", ""]
     st = os.path.join(src, "trace", "trace_kernel_stats.csv")
     if os.path.exists(st):
         lines += ["## --kernel-trace --stats", "", "| kernel | calls | total ms | avg us | % | min us | max us |", "|---|---:|---:|---:|---:|---:|---:|"]
