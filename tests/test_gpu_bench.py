@@ -49,3 +49,28 @@ def test_config_c5_is_labelled_depth_12():
     d = _bench("--config", "c5", "--prec", "f32", "--no-extras", "--no-cpu-baseline", "--no-alt-precision")
     assert "depth=12" in d["metric"] and d["config"]["max_depth"] == 12 and d["config"]["scene"] == "s4" and d["dtype"] == "f32"
     assert d["roofline"]["segments_per_sample"] > 1.0
+    assert d["roofline"]["parked_per_sample"] > 0          # the mesh lists are part of the algorithmic bytes
+
+
+def test_two_ranks_launched_the_driver_way_on_one_gpu():
+    """The N > 1 path of bench.py exactly as the driver starts it (torch.distributed.run, one process per rank) — on the one-GPU box both
+    ranks share GPU 0 and the exchange runs over gloo (--rehearse-on-one-gpu: not a measurement).  Weak scaling: spp 64 per rank, so the
+    frame is spp 128; every rank renders its interleaved stripes; ONE line, from rank 0, with the per-rank render / gather times."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-on-one-gpu"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["spp"] == 128 and "spp=128" in d["metric"]
+    assert d["config"]["samples_per_step"] == 1920 * 1080 * 128 and d["cpu_baseline"] is None and d["configs"] is None
+    p = d["per_rank"]
+    assert p["rows_per_rank"] == {"max": 544, "min": 536}                 # 135 stripes of 8 rows dealt to 2 ranks: 68 and 67
+    assert 0 < p["render_ms"]["min"] <= p["render_ms"]["max"] <= d["ms_per_step"] * 1.05 and p["gather_ms"]["max"] > 0
+    assert abs(d["value"] - d["config"]["samples_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
