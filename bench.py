@@ -51,7 +51,7 @@ def algorithmic_bytes(c, prec_bytes, kernel):
             + (3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes)
 
 
-KERNEL_SOURCES = ("spira_device.h", "spira_hip.hip", "spira_bvh.h")
+KERNEL_SOURCES = ("spira_device.h", "spira_hip.hip", "spira_bvh.h", "Makefile")       # (the Makefile: the two translation units differ in compiler flags)
 
 
 def kernel_source_hash():

@@ -2264,7 +2264,7 @@ __global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(
 }
 
 // Folds per-wave statistics rows into the render totals (used after k_path_metal, which has no resolve pass).
-__global__ void k_fold_stats(const uint32_t *blk_stats, uint32_t n_rows, Stats *stats) {
+static __global__ void k_fold_stats(const uint32_t *blk_stats, uint32_t n_rows, Stats *stats) {
     unsigned long long seg = 0, enq = 0, rmw = 0, sto = 0;
     for (uint32_t i = threadIdx.x; i < n_rows; i += blockDim.x) { seg += blk_stats[4 * i]; rmw += blk_stats[4 * i + 1]; sto += blk_stats[4 * i + 2]; enq += blk_stats[4 * i + 3]; }
     for (int sft = 32; sft > 0; sft >>= 1) { seg += __shfl_down(seg, sft); enq += __shfl_down(enq, sft); rmw += __shfl_down(rmw, sft); sto += __shfl_down(sto, sft); }

@@ -29,13 +29,29 @@
 #include "spira_bvh.h"
 #include "spira_validate.h"
 
+// The library is built from this one file as TWO translation units (Makefile): SPIRA_TU_MAIN — everything except the Float32 kernels, with the
+// compiler's defaults — and SPIRA_TU_F32 — render_impl<float> / trace_impl<float> and the kernels they launch, with -fno-slp-vectorize.  The SLP
+// vectoriser pairs Float32 operations into v_pk_mul/add/fma_f32 and pays for every pair with register moves: without it S1 runs 13 % and the
+// closed box S3 20 % faster in Float32; the Float64 kernels (no packed arithmetic to form) are indifferent or, on the mesh scene, 4 % better off
+// with it.  Neither macro defined (make stats, tests): one translation unit, as before.  The state below is shared by both units (inline variables
+// of a named namespace: one instance in the library); the functions further down are internal to each unit.
+#if defined(SPIRA_TU_MAIN) && defined(SPIRA_TU_F32)
+#error "SPIRA_TU_MAIN and SPIRA_TU_F32 are two different translation units"
+#endif
+struct spira_scene;
+namespace spira_tu {      // defined in the SPIRA_TU_F32 unit, called from the SPIRA_TU_MAIN one
+int render_impl_f32(const spira_scene *h, const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
+                    float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states);
+int trace_impl_f32(const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
+                   uint32_t n_paths, const uint32_t *ijs, int *prims, float *ts, float *dirs, float *radiance);
+}
 
-namespace {
+namespace spira_host {
 
-thread_local std::string tl_err;
-thread_local int tl_device = 0;
+inline thread_local std::string tl_err;
+inline thread_local int tl_device = 0;
 
-int fail(int code, const std::string &msg) { tl_err = msg; return code; }
+inline int fail(int code, const std::string &msg) { tl_err = msg; return code; }
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -91,9 +107,10 @@ struct Ctx {
 };
 
 constexpr int kMaxDevices = 16;
-Ctx g_ctx[kMaxDevices];
+inline Ctx g_ctx[kMaxDevices];
 
-}  // namespace
+}  // namespace spira_host
+using namespace spira_host;
 
 // The opaque scene handle of the C ABI (spira_scene_create_* / spira_scene_destroy).
 struct spira_scene {
@@ -799,6 +816,18 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     return 0;
 }
 
+// render_impl<T> of whichever translation unit holds the kernels of T
+template <class T>
+int render_entry(const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
+                 T *out_hdr, T *out_img, bool out_on_device, void *user_stream, bool progressive = false, uint32_t sample0 = 0, uint32_t *rng_states = nullptr) {
+#ifdef SPIRA_TU_MAIN
+    if constexpr (sizeof(T) == 4)
+        return spira_tu::render_impl_f32(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
+    else
+#endif
+        return render_impl<T>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
+}
+
 template <class T>
 int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
                uint32_t n_paths, const uint32_t *ijs, int *prims, T *ts, T *dirs, T *radiance) {
@@ -1102,13 +1131,13 @@ int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materia
             const spira_scene *hr = !mh ? nullptr : ((rehearse || r == 0) ? mh : mh->replica[r]);
             if (rows_r_all != max_rows) {
                 T *scratch = d_hdr + tile_elems;
-                if (int rc = render_impl<T>(hr, spheres5, materials8, triangles10, camera12, &tp, scratch, scratch + (size_t)3 * rows_r_all * W, true, st)) return rc;
+                if (int rc = render_entry<T>(hr, spheres5, materials8, triangles10, camera12, &tp, scratch, scratch + (size_t)3 * rows_r_all * W, true, st)) return rc;
                 hipError_t e = hipMemcpy2DAsync(d_hdr, (size_t)max_rows * W * sizeof(T), scratch, (size_t)rows_r_all * W * sizeof(T), (size_t)rows_r_all * W * sizeof(T), 6,
                                                 hipMemcpyDeviceToDevice, st);
                 if (e != hipSuccess) return fail(SPIRA_E_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e));
                 return 0;
             }
-            return render_impl<T>(hr, spheres5, materials8, triangles10, camera12, &tp, d_hdr, d_img, true, st);
+            return render_entry<T>(hr, spheres5, materials8, triangles10, camera12, &tp, d_hdr, d_img, true, st);
         };
         const int rc1 = phase1();
         if (rc1) bail(rc1);
@@ -1169,7 +1198,17 @@ int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materia
 
 }  // namespace
 
-// ======================================================================= C ABI
+#ifdef SPIRA_TU_F32
+int spira_tu::render_impl_f32(const spira_scene *h, const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
+                              float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states) {
+    return render_impl<float>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
+}
+int spira_tu::trace_impl_f32(const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
+                             uint32_t n_paths, const uint32_t *ijs, int *prims, float *ts, float *dirs, float *radiance) {
+    return trace_impl<float>(spheres5, materials8, triangles10, camera12, p, n_paths, ijs, prims, ts, dirs, radiance);
+}
+#else
+// ======================================================================= C ABI (SPIRA_TU_MAIN, or the single translation unit)
 extern "C" {
 
 int spira_abi_version(void) { return SPIRA_ABI_VERSION; }
@@ -1266,39 +1305,39 @@ int spira_camera_lookat_f64(const double position[3], const double look_at[3], c
 }
 
 int spira_render_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, float *out_hdr, float *out_img) {
-    return render_impl<float>(nullptr, s, m, t, cam, p, out_hdr, out_img, false, nullptr);
+    return render_entry<float>(nullptr, s, m, t, cam, p, out_hdr, out_img, false, nullptr);
 }
 int spira_render_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, double *out_hdr, double *out_img) {
-    return render_impl<double>(nullptr, s, m, t, cam, p, out_hdr, out_img, false, nullptr);
+    return render_entry<double>(nullptr, s, m, t, cam, p, out_hdr, out_img, false, nullptr);
 }
 int spira_render_device_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, float *d_hdr,
                             float *d_img, void *stream) {
-    return render_impl<float>(nullptr, s, m, t, cam, p, d_hdr, d_img, true, stream);
+    return render_entry<float>(nullptr, s, m, t, cam, p, d_hdr, d_img, true, stream);
 }
 int spira_render_device_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, double *d_hdr,
                             double *d_img, void *stream) {
-    return render_impl<double>(nullptr, s, m, t, cam, p, d_hdr, d_img, true, stream);
+    return render_entry<double>(nullptr, s, m, t, cam, p, d_hdr, d_img, true, stream);
 }
 
 int spira_accumulate_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t sample0,
                          float *sum_rgb, uint32_t *rng_states) {
     if (!sum_rgb) return fail(SPIRA_E_INVALID, "sum_rgb is NULL");
-    return render_impl<float>(nullptr, s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
+    return render_entry<float>(nullptr, s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
 }
 int spira_accumulate_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t sample0,
                          double *sum_rgb, uint32_t *rng_states) {
     if (!sum_rgb) return fail(SPIRA_E_INVALID, "sum_rgb is NULL");
-    return render_impl<double>(nullptr, s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
+    return render_entry<double>(nullptr, s, m, t, cam, p, sum_rgb, nullptr, false, nullptr, true, sample0, rng_states);
 }
 int spira_accumulate_device_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t sample0,
                                 float *d_sum_rgb, uint32_t *d_rng_states, void *stream) {
     if (!d_sum_rgb) return fail(SPIRA_E_INVALID, "d_sum_rgb is NULL");
-    return render_impl<float>(nullptr, s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
+    return render_entry<float>(nullptr, s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
 }
 int spira_accumulate_device_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t sample0,
                                 double *d_sum_rgb, uint32_t *d_rng_states, void *stream) {
     if (!d_sum_rgb) return fail(SPIRA_E_INVALID, "d_sum_rgb is NULL");
-    return render_impl<double>(nullptr, s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
+    return render_entry<double>(nullptr, s, m, t, cam, p, d_sum_rgb, nullptr, true, stream, true, sample0, d_rng_states);
 }
 
 // ---- scene handles: validate + build + upload once, render many times
@@ -1344,19 +1383,19 @@ int spira_scene_destroy(spira_scene *scene) {
 }
 int spira_render_scene_f32(const spira_scene *scene, const float cam[12], const spira_params *p, float *out_hdr, float *out_img) {
     if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
-    return render_impl<float>(scene, nullptr, nullptr, nullptr, cam, p, out_hdr, out_img, false, nullptr);
+    return render_entry<float>(scene, nullptr, nullptr, nullptr, cam, p, out_hdr, out_img, false, nullptr);
 }
 int spira_render_scene_f64(const spira_scene *scene, const double cam[12], const spira_params *p, double *out_hdr, double *out_img) {
     if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
-    return render_impl<double>(scene, nullptr, nullptr, nullptr, cam, p, out_hdr, out_img, false, nullptr);
+    return render_entry<double>(scene, nullptr, nullptr, nullptr, cam, p, out_hdr, out_img, false, nullptr);
 }
 int spira_render_scene_device_f32(const spira_scene *scene, const float cam[12], const spira_params *p, float *d_hdr, float *d_img, void *stream) {
     if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
-    return render_impl<float>(scene, nullptr, nullptr, nullptr, cam, p, d_hdr, d_img, true, stream);
+    return render_entry<float>(scene, nullptr, nullptr, nullptr, cam, p, d_hdr, d_img, true, stream);
 }
 int spira_render_scene_device_f64(const spira_scene *scene, const double cam[12], const spira_params *p, double *d_hdr, double *d_img, void *stream) {
     if (!scene) return fail(SPIRA_E_INVALID, "scene handle is NULL or was destroyed");
-    return render_impl<double>(scene, nullptr, nullptr, nullptr, cam, p, d_hdr, d_img, true, stream);
+    return render_entry<double>(scene, nullptr, nullptr, nullptr, cam, p, d_hdr, d_img, true, stream);
 }
 
 // ---- multi-device render on one node: interleaved 8-row stripes, one host thread + stream per device, one RCCL gather
@@ -1371,7 +1410,11 @@ int spira_render_multi_f64(const double *s, const double *m, const double *t, co
 
 int spira_trace_paths_f32(const float *s, const float *m, const float *t, const float cam[12], const spira_params *p, uint32_t n_paths,
                           const uint32_t *ijs, int *prims, float *ts, float *dirs, float *radiance) {
+#ifdef SPIRA_TU_MAIN
+    return spira_tu::trace_impl_f32(s, m, t, cam, p, n_paths, ijs, prims, ts, dirs, radiance);
+#else
     return trace_impl<float>(s, m, t, cam, p, n_paths, ijs, prims, ts, dirs, radiance);
+#endif
 }
 int spira_trace_paths_f64(const double *s, const double *m, const double *t, const double cam[12], const spira_params *p, uint32_t n_paths,
                           const uint32_t *ijs, int *prims, double *ts, double *dirs, double *radiance) {
@@ -1391,3 +1434,4 @@ uint32_t spira_stripe_rows(uint32_t height, uint32_t stripe_h, uint32_t stripe_c
 }
 
 }  // extern "C"
+#endif  // !SPIRA_TU_F32
