@@ -105,6 +105,12 @@ def test_validation_errors(binding):
             binding.render(spheres, mats, None, cam, params)
         return str(e.value)
     assert "error -1" in rc(binding.make_params(1, 10, 1, 1, 5, 5))                      # width < 2
+    # the message is set inside render_impl<T> — for Float32 that is the library's OTHER translation unit — and read through spira_last_error():
+    # both units must see one thread-local error string
+    for prec in ("f32", "f64"):
+        with pytest.raises(binding.SpiraError) as e:
+            binding.render(sp, ma, None, cam, binding.make_params(1, 10, 1, 1, 5, 5), prec)
+        assert "width and height must be >= 2" in str(e.value), prec
     assert "error -4" in rc(binding.make_params(8, 8, 0, 1, 5, 5))                       # spp = 0
     assert "error -4" in rc(binding.make_params(8, 8, 1, 256, 5, 5))                     # depth > 255
     assert "error -4" in rc(binding.make_params(8, 8, 1, 1, 2000, 5))                    # too many spheres
