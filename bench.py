@@ -189,6 +189,9 @@ def main():
     # the committed PMC summaries were taken at 1080p with 64 sample slots per pass on one GPU: any spp that is a multiple of 64 launches the same shape
     pmc_shape = (W, H, world) == (1920, 1080, 1) and spp_total % 64 == 0 and depth == cfg["depth"]
     src_hash = kernel_source_hash()
+    lib_id = B.build_id()          # the sources the LOADED library was built from: a library older than the files on disk gets no PMC figures either
+    if lib_id != src_hash:
+        src_hash = "library:" + lib_id
 
     def workload(name):
         s = builders[name]()

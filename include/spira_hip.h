@@ -161,6 +161,7 @@ typedef struct spira_counters {
 
 /* ---- library / device ---- */
 int         spira_abi_version(void);
+const char *spira_build_id(void);             /* first 16 hex digits of the SHA-256 of the kernel sources + Makefile this library was built from (bench.py: which profile belongs to it) */
 const char *spira_last_error(void);
 int         spira_device_count(void);
 int         spira_set_device(int device);      /* device used by subsequent calls on this thread */

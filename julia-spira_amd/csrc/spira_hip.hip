@@ -1212,6 +1212,10 @@ int spira_tu::trace_impl_f32(const float *spheres5, const float *materials8, con
 extern "C" {
 
 int spira_abi_version(void) { return SPIRA_ABI_VERSION; }
+#ifndef SPIRA_BUILD_ID
+#define SPIRA_BUILD_ID "unknown"
+#endif
+const char *spira_build_id(void) { return SPIRA_BUILD_ID; }
 const char *spira_last_error(void) { return tl_err.c_str(); }
 
 int spira_device_count(void) {

@@ -25,7 +25,7 @@ FLAG_PROFILE = 0x10000
 EXT_DIELECTRIC, EXT_SPECTRAL = 0x20000, 0x40000
 
 EXPORTS = [
-    "spira_abi_version", "spira_last_error", "spira_device_count", "spira_set_device", "spira_get_counters",
+    "spira_abi_version", "spira_build_id", "spira_last_error", "spira_device_count", "spira_set_device", "spira_get_counters",
     "spira_shutdown", "spira_camera_lookat_f32", "spira_camera_lookat_f64", "spira_render_f32", "spira_render_f64",
     "spira_render_device_f32", "spira_render_device_f64", "spira_trace_paths_f32", "spira_trace_paths_f64",
     "spira_tonemap_f32", "spira_stripe_rows", "spira_accumulate_f32", "spira_accumulate_f64", "spira_accumulate_device_f32",
@@ -77,6 +77,7 @@ def lib():
             pass
         _lib = C.CDLL(LIB_PATH)
         _lib.spira_last_error.restype = C.c_char_p
+        _lib.spira_build_id.restype = C.c_char_p
         _lib.spira_stripe_rows.restype = C.c_uint32
         _lib.spira_stripe_rows.argtypes = [C.c_uint32] * 4
         for name in EXPORTS:
@@ -86,6 +87,11 @@ def lib():
             _lib = None
             raise SpiraError("%s has ABI version %d, this binding was written for %d" % (LIB_PATH, have, ABI_VERSION))
     return _lib
+
+
+def build_id():
+    """Hash of the kernel sources the loaded library was built from (csrc/Makefile); bench.py attaches PMC figures of exactly these sources."""
+    return lib().spira_build_id().decode()
 
 
 def _check(rc):

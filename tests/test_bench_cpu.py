@@ -94,3 +94,11 @@ def test_c4_tile_arithmetic_on_8_gpus():
     rows = [D.tile_params(1080, 8, r)["rows"] for r in range(8)]
     assert sum(rows) == 1080 and max(rows) - min(rows) <= 8 and all(128 <= x <= 136 for x in rows)
     assert bench.CONFIGS["c4"]["scaling"] == "strong"      # spp_total = spp (not spp * world): bench.py main()
+
+
+def test_the_library_carries_the_hash_of_the_sources_it_was_built_from():
+    """spira_build_id() (csrc/Makefile: sha256 of the kernel sources + the Makefile) is what bench.py compares with the hash of the files on disk and with the
+    `source_hash` of a committed PMC summary: figures measured on other sources — or a library older than its sources — never reach a bench line."""
+    sys.path.insert(0, os.path.join(ROOT, "julia-spira_amd"))
+    from spira_hip import _binding as B
+    assert B.build_id() == bench.kernel_source_hash() and len(B.build_id()) == 16
