@@ -364,7 +364,7 @@ def main():
                 hdr_host, _ = B.render(sc[0], sc[1], sc[2], sc[3], params, args.prec)
             e2e = (time.perf_counter() - t1) / 3
             end_to_end = {"ms": round(e2e * 1e3, 3), "value": round(samples_per_step / e2e / 1e6, 3), "unit": "Msamples/s", "d2h_bytes": int(hdr_host.nbytes),
-                          "what": "spira_render_%s with host pointers: scene validation + upload, kernels, one D2H copy of the planar frame into pageable memory, synchronous" % args.prec}
+                          "what": "spira_render_%s with host pointers: scene validation + upload, kernels, the planar frame to pageable host memory (device -> pinned staging in chunks, host threads move them on), synchronous" % args.prec}
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -1,6 +1,7 @@
 """GPU (MI355X): host-runtime contracts of the C ABI — stream ordering of the shared workspaces, scene handles,
 large LDS scenes, progressive accumulation against the ORACLE (not only against the HIP one-shot)."""
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -148,3 +149,30 @@ def test_progressive_metal_needs_rng_states(gpu):
     gpu.accumulate(s["spheres5"], s["materials8"], None, s["camera12"], gpu.make_params(64, 36, 2, 4, 5, 5, 0, flags=gpu.SEM_METAL, seed=1), 0, sums, None, "f32")
     with pytest.raises(gpu.SpiraError, match="rng_states"):
         gpu.accumulate(s["spheres5"], s["materials8"], None, s["camera12"], gpu.make_params(64, 36, 2, 4, 5, 5, 0, flags=gpu.SEM_METAL, seed=1), 2, sums, None, "f32")
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_host_outputs_through_the_staged_copy_equal_device_outputs(gpu, prec):
+    """Frames of 4 MB and more reach a host-pointer caller through pinned staging in chunks, moved on by several host threads (copy_out): both outputs, a
+    size that is no multiple of the chunk, any thread count / chunk size — bit for bit what the device-output entry leaves on the device; a small frame
+    takes the plain copy."""
+    import torch
+    s = scenes.scene_s2()
+    ns, nm, nt = _counts(s)
+    tdt = torch.float64 if prec == "f64" else torch.float32
+    for W, H in ((1500, 1101), (160, 90)):
+        p = gpu.make_params(W, H, 2, 4, ns, nm, nt, seed=9)
+        d_hdr = torch.empty((3, H, W), dtype=tdt, device="cuda")
+        d_img = torch.empty((3, H, W), dtype=tdt, device="cuda")
+        gpu.render_device(*_args(s), p, d_hdr.data_ptr(), d_img.data_ptr(), torch.cuda.current_stream().cuda_stream, prec)
+        torch.cuda.synchronize()
+        for env in ({}, {"SPIRA_STAGE_THREADS": "1"}, {"SPIRA_STAGE_THREADS": "7", "SPIRA_STAGE_CHUNK_MB": "3"}, {"SPIRA_STAGE_CHUNK_MB": "1000"}):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                hdr, img = gpu.render(*_args(s), p, prec, want_img=True)
+                only_img = gpu.render(*_args(s), p, prec, want_hdr=False, want_img=True)[1]
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            assert np.array_equal(hdr, d_hdr.cpu().numpy()) and np.array_equal(img, d_img.cpu().numpy()) and np.array_equal(only_img, img), (W, H, env)
