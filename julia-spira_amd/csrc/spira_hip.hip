@@ -29,14 +29,19 @@
 #include "spira_bvh.h"
 #include "spira_validate.h"
 
-// The library is built from this one file as TWO translation units (Makefile): SPIRA_TU_MAIN — everything except the Float32 kernels, with the
-// compiler's defaults — and SPIRA_TU_F32 — render_impl<float> / trace_impl<float> and the kernels they launch, with -fno-slp-vectorize.  The SLP
-// vectoriser pairs Float32 operations into v_pk_mul/add/fma_f32 and pays for every pair with register moves: without it S1 runs 13 % and the
-// closed box S3 20 % faster in Float32; the Float64 kernels (no packed arithmetic to form) are indifferent or, on the mesh scene, 4 % better off
-// with it.  Neither macro defined (make stats, tests): one translation unit, as before.  The state below is shared by both units (inline variables
-// of a named namespace: one instance in the library); the functions further down are internal to each unit.
-#if defined(SPIRA_TU_MAIN) && defined(SPIRA_TU_F32)
-#error "SPIRA_TU_MAIN and SPIRA_TU_F32 are two different translation units"
+// The library is built from this one file as THREE translation units (Makefile), because what the optimiser does to one family of kernels it undoes
+// on another (profiles/r03_compiler_flags.md):
+//   SPIRA_TU_F32      render_impl<float> / trace_impl<float> and every kernel they launch, with -fno-slp-vectorize.  The SLP vectoriser pairs Float32
+//                     operations into v_pk_mul/add/fma_f32 and pays for every pair with register moves: without it S1 runs 13 % and the closed box S3
+//                     20 % faster in Float32 (Float64 has no packed arithmetic to form: indifferent, the mesh scene 4 % better off WITH the pass).
+//   SPIRA_TU_F64MESH  the Float64 path kernels of mesh scenes (k_path<double, ., BVH = true, ...>), with the compiler's defaults.
+//   SPIRA_TU_MAIN     the C ABI, the host runtime and every other Float64 kernel, with -mllvm -two-entry-phi-node-folding-threshold=1: SimplifyCFG then
+//                     turns far fewer two-sided branches into selects, which is 4 % of k_path on S1 in Float64 (1 % on the closed box) — and 5.5 % the
+//                     other way on the mesh kernels, hence their own unit.  (No effect on the Float32 kernels or the secondary Float64 ones.)
+// None of the macros defined (make stats, tests): one translation unit, the compiler's defaults.  The state below is shared by all units (inline
+// variables of a named namespace: one instance in the library); the functions further down are internal to each unit.
+#if (defined(SPIRA_TU_MAIN) + defined(SPIRA_TU_F32) + defined(SPIRA_TU_F64MESH)) > 1
+#error "SPIRA_TU_MAIN, SPIRA_TU_F32 and SPIRA_TU_F64MESH are three different translation units"
 #endif
 struct spira_scene;
 namespace spira_tu {      // defined in the SPIRA_TU_F32 unit, called from the SPIRA_TU_MAIN one
@@ -44,12 +49,16 @@ int render_impl_f32(const spira_scene *h, const float *spheres5, const float *ma
                     float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states);
 int trace_impl_f32(const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
                    uint32_t n_paths, const uint32_t *ijs, int *prims, float *ts, float *dirs, float *radiance);
+// defined in the SPIRA_TU_F64MESH unit: launch_path<double> of a mesh scene (PathArgs::mesh_mode 0 or 1) and launch_path_resume<double> (mode 2)
+int launch_path_mesh_f64(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<double> &a, int spec);
+void launch_path_resume_f64(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<double> &a);
 }
 
 namespace spira_host {
 
 inline thread_local std::string tl_err;
 inline thread_local int tl_device = 0;
+inline thread_local hipError_t tl_lds_optin = hipSuccess;      // a refused LDS opt-in of this thread's call (launch_lds / lds_optin_failed), whichever unit launched
 
 inline int fail(int code, const std::string &msg) { tl_err = msg; return code; }
 
@@ -323,7 +332,6 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
 
 // Launch with a dynamic LDS block; above 64 KB the function has to be told first (up to the CU's 160 KB).
 // A refused opt-in is remembered (thread-local) and turned into SPIRA_E_LIMIT by lds_optin_failed() before the call returns.
-thread_local hipError_t tl_lds_optin = hipSuccess;
 template <class K, class... Args>
 void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
     if (lds > 64 * 1024) {
@@ -389,8 +397,14 @@ int launch_path_mode(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathAr
 template <class T>
 int launch_path(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<T> &a, int spec) {
     if (!a.scene.n_bvh_tris) return launch_path_mode<T, false, 0>(R, grid, lds, st, a, spec);
-    if (a.mesh_mode == 1) return launch_path_mode<T, true, 1>(R, grid, lds, st, a, spec);
-    return launch_path_mode<T, true, 0>(R, grid, lds, st, a, spec);
+#ifdef SPIRA_TU_MAIN
+    if constexpr (sizeof(T) == 8) return spira_tu::launch_path_mesh_f64(R, grid, lds, st, a, spec);
+    else
+#endif
+    {
+        if (a.mesh_mode == 1) return launch_path_mode<T, true, 1>(R, grid, lds, st, a, spec);
+        return launch_path_mode<T, true, 0>(R, grid, lds, st, a, spec);
+    }
 }
 
 // the second launch of a mesh pass (PathArgs::mesh_mode 2): the exact instantiation — its waves add to radiance the first launch
@@ -404,6 +418,16 @@ void launch_path_resume(int R, dim3 grid, size_t lds, hipStream_t st, spira::Pat
     else if (R == 2 && a.scene.n_triangles) launch_lds(spira::k_path<T, 2, true, false, false, 2, true>, grid, blk, lds, st, a);
     else if (R == 2) launch_lds(spira::k_path<T, 2, true, false, false, 2, false>, grid, blk, lds, st, a);
     else launch_lds(spira::k_path<T, 1, true, false, false, 2>, grid, blk, lds, st, a);
+}
+
+// launch_path_resume<T> of whichever translation unit holds the mesh kernels of T
+template <class T>
+void launch_path_resume_entry(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<T> &a) {
+#ifdef SPIRA_TU_MAIN
+    if constexpr (sizeof(T) == 8) spira_tu::launch_path_resume_f64(R, grid, lds, st, a);
+    else
+#endif
+        launch_path_resume<T>(R, grid, lds, st, a);
 }
 
 int profile_events(Ctx &c, size_t need) {
@@ -433,18 +457,19 @@ int mark_done(Ctx &c, hipStream_t st) {
 // (most of what is left is the first touch of the caller's freshly allocated pages, which no copy strategy removes).
 // Synchronous (the host-pointer entries are); small outputs take the plain copy.  Returns with the stream drained up to the copies.
 int copy_out(Ctx &c, hipStream_t st, void *const dst[2], const void *const src[2], size_t bytes_each) {
-    const size_t kChunk = (size_t)std::max<uint32_t>(1, env_u32("SPIRA_STAGE_CHUNK_MB", 8)) << 20, kMinStaged = 4u << 20;      // (threads and chunk size: flat between 4 and 16 threads, 2 and 8 MB)
+    const size_t kChunk = (size_t)std::max<uint32_t>(1, env_u32("SPIRA_STAGE_CHUNK_MB", 8)) << 20, kMinStaged = 4u << 20, kMaxStaged = 512u << 20;      // (threads and chunk size: flat between 4 and 16 threads, 2 and 8 MB; frames beyond 512 MB take the plain copy rather than pin as much host memory)
     const int n_out = (dst[0] ? 1 : 0) + (dst[1] ? 1 : 0);
     if (!n_out) return 0;
-    if (bytes_each < kMinStaged) {
+    const size_t total = bytes_each * (size_t)n_out;
+    bool staged = bytes_each >= kMinStaged && total <= kMaxStaged;
+    if (staged && c.h_stage_cap < total) {
+        if (c.h_stage) { (void)hipHostFree(c.h_stage); c.h_stage = nullptr; c.h_stage_cap = 0; }
+        if (hipHostMalloc(&c.h_stage, total, hipHostMallocDefault) == hipSuccess) c.h_stage_cap = total;
+        else { c.h_stage = nullptr; (void)hipGetLastError(); staged = false; }      // no pinned memory to be had: the plain copy still works
+    }
+    if (!staged) {
         for (int k = 0; k < 2; ++k) if (dst[k]) HIP_TRY(hipMemcpyAsync(dst[k], src[k], bytes_each, hipMemcpyDeviceToHost, st));
         return 0;
-    }
-    const size_t total = bytes_each * (size_t)n_out;
-    if (c.h_stage_cap < total) {
-        if (c.h_stage) { (void)hipHostFree(c.h_stage); c.h_stage = nullptr; c.h_stage_cap = 0; }
-        HIP_TRY(hipHostMalloc(&c.h_stage, total, hipHostMallocDefault));
-        c.h_stage_cap = total;
     }
     struct Piece { char *dst; size_t off, len; };
     std::vector<Piece> pieces;
@@ -806,7 +831,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                     spira::PathArgs<T> pb = pa;
                     pb.mesh_mode = 2; pb.n_first = 0;
                     const uint32_t nwb = pa.resume_nw / pa.resume_k;
-                    launch_path_resume<T>(R, dim3((nwb + wpb - 1) / wpb), lds_a, st, pb);
+                    launch_path_resume_entry<T>(R, dim3((nwb + wpb - 1) / wpb), lds_a, st, pb);
                     ++launches;
                 }
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
@@ -1257,7 +1282,15 @@ int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materia
 
 }  // namespace
 
-#ifdef SPIRA_TU_F32
+#ifdef SPIRA_TU_F64MESH
+int spira_tu::launch_path_mesh_f64(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<double> &a, int spec) {
+    if (a.mesh_mode == 1) return launch_path_mode<double, true, 1>(R, grid, lds, st, a, spec);
+    return launch_path_mode<double, true, 0>(R, grid, lds, st, a, spec);
+}
+void spira_tu::launch_path_resume_f64(int R, dim3 grid, size_t lds, hipStream_t st, const spira::PathArgs<double> &a) {
+    launch_path_resume<double>(R, grid, lds, st, a);
+}
+#elif defined(SPIRA_TU_F32)
 int spira_tu::render_impl_f32(const spira_scene *h, const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
                               float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states) {
     return render_impl<float>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
@@ -1500,4 +1533,4 @@ uint32_t spira_stripe_rows(uint32_t height, uint32_t stripe_h, uint32_t stripe_c
 }
 
 }  // extern "C"
-#endif  // !SPIRA_TU_F32
+#endif  // SPIRA_TU_MAIN, or the single translation unit

@@ -43,24 +43,31 @@ def test_library_is_gfx950_only():
         assert b"gfx950" in blob and b"gfx942" not in blob and b"gfx90a" not in blob
 
 
-def test_the_two_translation_units_split_the_kernels_by_precision():
-    """csrc/Makefile builds spira_hip.hip twice: SPIRA_TU_F32 (-fno-slp-vectorize) must hold every Float32 path kernel and no Float64 one, SPIRA_TU_MAIN
-    the reverse — a Float32 kernel instantiated in the main unit would silently run the slower code (profiles/r03_compiler_flags.md)."""
+def test_the_translation_units_hold_the_kernels_they_are_built_for():
+    """csrc/Makefile builds spira_hip.hip three times: SPIRA_TU_F32 (-fno-slp-vectorize) must hold every Float32 kernel and no Float64 one,
+    SPIRA_TU_F64MESH (compiler defaults) the Float64 path kernels of mesh scenes and nothing else, SPIRA_TU_MAIN (fewer branches folded into selects) every
+    other Float64 kernel — a kernel instantiated in the wrong unit would silently run the slower code (profiles/r03_compiler_flags.md)."""
     import subprocess
     csrc = os.path.join(ROOT, "julia-spira_amd", "csrc")
-    objs = {n: os.path.join(csrc, "spira_tu_%s.o" % n) for n in ("main", "f32")}
+    objs = {n: os.path.join(csrc, "spira_tu_%s.o" % n) for n in ("main", "f32", "f64mesh")}
     if not all(os.path.exists(o) for o in objs.values()):
         pytest.skip("objects not present (library built elsewhere)")
     syms = {n: subprocess.run(["nm", o], capture_output=True, text=True, check=True).stdout for n, o in objs.items()}
     count = lambda text, pat: len(re.findall(pat, text))
-    # host stubs of the kernel templates: k_path<float ...> mangles to ...6k_pathIf..., k_path<double ...> to ...6k_pathId...
-    for kern in ("6k_path", "8k_bounce", "6k_mega", "9k_resolve", "10k_finalize", "15k_variant_metal", "13k_variant_cpu", "12k_path_metal"):
+    # host stubs of the kernel templates: k_path<float ...> mangles to ...6k_pathIf..., k_path<double, R, BVH, ...> to ...6k_pathIdLi<R>ELb<BVH>E...
+    for kern in ("8k_bounce", "6k_mega", "9k_resolve", "10k_finalize", "15k_variant_metal", "13k_variant_cpu", "12k_path_metal"):
         assert count(syms["main"], kern + "If") == 0 and count(syms["main"], kern + "Id") > 0, kern
         assert count(syms["f32"], kern + "Id") == 0 and count(syms["f32"], kern + "If") > 0, kern
-    assert "render_impl_f32" in syms["f32"] and " T " in [ln[16:19] for ln in syms["f32"].splitlines() if "render_impl_f32" in ln]
-    assert re.search(r" U .*render_impl_f32", syms["main"]) and not re.search(r" T spira_render_f32", syms["f32"])
+        assert count(syms["f64mesh"], kern + "I[fd]") == 0, kern
+    assert count(syms["f32"], "6k_pathIf") > 0 and count(syms["f32"], "6k_pathId") == 0
+    assert count(syms["main"], "6k_pathIf") == 0 and count(syms["main"], "6k_pathIdLi[12]ELb0E") > 0 and count(syms["main"], "6k_pathIdLi[12]ELb1E") == 0
+    assert count(syms["f64mesh"], "6k_pathIf") == 0 and count(syms["f64mesh"], "6k_pathIdLi[12]ELb1E") > 0 and count(syms["f64mesh"], "6k_pathIdLi[12]ELb0E") == 0
+    for fn, unit in (("render_impl_f32", "f32"), ("trace_impl_f32", "f32"), ("launch_path_mesh_f64", "f64mesh"), ("launch_path_resume_f64", "f64mesh")):
+        assert re.search(r" T .*%s" % fn, syms[unit]) and re.search(r" U .*%s" % fn, syms["main"]), fn
+    assert not re.search(r" T spira_render_f32", syms["f32"]) and not re.search(r" T spira_render_f64", syms["f64mesh"])
     mk = open(os.path.join(csrc, "Makefile")).read()
-    assert "-DSPIRA_TU_F32" in mk and "-fno-slp-vectorize" in mk and "-DSPIRA_TU_MAIN" in mk
+    for flag in ("-DSPIRA_TU_F32", "-fno-slp-vectorize", "-DSPIRA_TU_MAIN", "-DSPIRA_TU_F64MESH", "-two-entry-phi-node-folding-threshold=1"):
+        assert flag in mk, flag
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
