@@ -176,3 +176,45 @@ def test_host_outputs_through_the_staged_copy_equal_device_outputs(gpu, prec):
                 for k, v in old.items():
                     os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             assert np.array_equal(hdr, d_hdr.cpu().numpy()) and np.array_equal(img, d_img.cpu().numpy()) and np.array_equal(only_img, img), (W, H, env)
+
+
+def test_concurrent_host_threads_share_one_device_context(gpu):
+    """Four host threads render at once on the same device — both precisions (two translation units of the library), host-array and scene-handle entries,
+    different image sizes — and one of them keeps provoking validation errors: the context's mutex serialises the workspaces, the error string and the
+    counters stay per thread / per call, and every image equals the one the same call gives alone."""
+    import threading
+    jobs = []
+    for i, (builder, prec, W, H, spp, depth) in enumerate(((scenes.scene_s1, "f32", 1500, 1101, 1, 4), (scenes.scene_s2, "f64", 1100, 700, 1, 4),      # (two frames big enough for the staged host copy)
+                                                            (lambda: scenes.scene_s4(level=3), "f32", 128, 72, 2, 7), (scenes.scene_s3, "f64", 64, 36, 2, 8))):
+        s = builder()
+        p = gpu.make_params(W, H, spp, depth, *_counts(s), seed=40 + i)
+        ref, _ = gpu.render(*_args(s), p, prec)
+        jobs.append((s, prec, p, ref))
+    errors = []
+
+    def worker(k):
+        s, prec, p, ref = jobs[k]
+        try:
+            h = gpu.Scene(s["spheres5"], s["materials8"], s["triangles10"], prec) if k % 2 else None
+            for it in range(8):
+                hdr = (h.render(s["camera12"], p) if h else gpu.render(*_args(s), p, prec))[0]
+                if not np.array_equal(hdr, ref):
+                    errors.append((k, it, "image differs"))
+                if k == 0:                               # an error on this thread must leave the others' calls and messages alone
+                    try:
+                        gpu.render(*_args(s), gpu.make_params(1, 10, 1, 1, *_counts(s)), prec)
+                        errors.append((k, it, "no error raised"))
+                    except gpu.SpiraError as e:
+                        if "width and height" not in str(e):
+                            errors.append((k, it, str(e)))
+            if h:
+                h.destroy()
+        except Exception as e:                           # noqa: BLE001 (reported below)
+            errors.append((k, "exception", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
