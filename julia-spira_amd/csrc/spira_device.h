@@ -1259,13 +1259,14 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
     // stay in registers and go straight into their next stage instead of through the queue — compaction only where it pays (a closed
     // scene never touches the queues; an open one compacts as before).  Packets then carry their own stage (7 bits above the hit
     // reference), because a wave's region may hold hits of different segments.
-    const bool mixed = rc.max_depth <= 128u;
+    const bool mixed = mesh_mode != 0u || rc.max_depth <= 128u;      // (the two launches of a mesh pass exist for max_depth <= 128 only: a compile-time fact there,
     const uint32_t dense_pct = mixed ? a.dense_pct : 0u;
     // Deferred mesh traversal (BVH scenes, max_depth <= 128): a ray that reaches the mesh's bounding box is not traversed where it
     // stands — a few lanes of every wave would walk the tree in global memory while the others wait — but parked on the wave's
     // mesh list; sessions (below) walk the parked rays with all 64 lanes, refilled as rays finish; a hit then enters the out queue as a
     // packet of its own stage.  (On the 81 920-triangle scene of config 5 the in-place traversal was 70 % of the frame time.)
-    const bool defer = BVH && mixed && a.mesh_list != nullptr;
+    const bool defer = mesh_mode != 0u || (BVH && mixed && a.mesh_list != nullptr);      //  and so is `defer`: neither launch carries the in-place traversal or the stage-less packets of deeper
+                                                                                         //  renders — config 5: Float32 4.05 -> 3.88 ms, Float64 5.26 -> 5.11 ms, no spilled VGPR left in the Float64 kernels)
     Pack4<T> *mlist = a.mesh_list + 3 * (size_t)region;
     uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0, n_park = 0;   // (n_park: entries written to the mesh list, wave-uniform)
     uint32_t n_in = 0;                                           // packets waiting in this wave's region (rounds >= 1)
