@@ -1213,14 +1213,15 @@ __device__ unsigned long long g_mesh_dbg[32];        // [16..31]: the same for t
 #ifndef SPIRA_WAVES_B_F32
 #define SPIRA_WAVES_B_F32 4      // the second launch of a mesh pass runs 16 fat waves per CU = 4 per SIMD whatever the kernel allows: 128 registers instead of 96
 #endif                           // (35 spilled VGPRs less) is config 5 Float32 4.33 -> 4.11 ms.  (The parking launch with 4 / 3 waves per SIMD: +2 % / +4 % frame time.)
-#ifndef SPIRA_WAVES_NOMESH_F32
-#define SPIRA_WAVES_NOMESH_F32 6 // Float32 scenes without a BVH mesh: the instantiation with the LDS triangle scan wants 90 registers at 5 waves per SIMD; held to 80 it runs
-#endif                           // 6 (closed box S3: 19.6 -> 18.6 ms); the one without the scan (S1) takes 75 either way; the mesh instantiations lose 6 % at 6
 #ifndef SPIRA_WAVES_B_F64
 #define SPIRA_WAVES_B_F64 SPIRA_WAVES_F64
 #endif
+#ifndef SPIRA_WAVES_PATH_F32
+#define SPIRA_WAVES_PATH_F32 6   // the Float32 path kernels (k_path but its second mesh launch, k_path_metal) at 6 waves per SIMD = 80 registers: the instantiation with the LDS triangle
+#endif                           // scan wants 90 at 5 (closed box S3: 19.6 -> 18.6 ms), the mesh parking launch 82 (config 5: 3.87 -> 3.81 ms; before the in-place traversal left it, it wanted
+                                 // 96 + 35 spilled and lost 6 % at 6), S1's takes 75 either way, k_path_metal 47-53.  (k_bounce stays at SPIRA_WAVES_F32: it loses at 6.)
 template <class T, int R, bool BVH, bool EXT, bool SPEC, int MODE = 0, bool TRI = true>
-__global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B_F64 : SPIRA_WAVES_B_F32) : ((!BVH && sizeof(T) == 4) ? SPIRA_WAVES_NOMESH_F32 : SPIRA_WAVES_PER_SIMD(T))) void k_path(const PathArgs<T> a) {
+__global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B_F64 : SPIRA_WAVES_B_F32) : (sizeof(T) == 4 ? SPIRA_WAVES_PATH_F32 : SPIRA_WAVES_F64)) void k_path(const PathArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
     constexpr bool kRefArray = sizeof(T) == 4;
@@ -2129,7 +2130,7 @@ template <class T> struct MetalArgs {
 };
 
 template <class T, int R, bool SPEC>
-__global__ __launch_bounds__(kBlock, SPIRA_WAVES_PER_SIMD(T)) void k_path_metal(const MetalArgs<T> a) {
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? SPIRA_WAVES_PATH_F32 : SPIRA_WAVES_F64) void k_path_metal(const MetalArgs<T> a) {
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
