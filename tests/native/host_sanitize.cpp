@@ -56,6 +56,8 @@ template <class T> static uint32_t bits_of(T w) {
 
 // Host mirror of the kernels' walk (spira_device.h: bvh8_enter / bvh8_node / bvh8_step): root box in T, child boxes in Float32 in the
 // normalised frame with 1/d clamped to 2^40, hit children in ascending (slot ^ octant) order, triangles in T on the caller's coordinates.
+// (One item per trip, as the Float64 kernel walks; the Float32 kernel takes a node's last pending triangle and the next node in one trip — the same sets of
+// nodes and triangles up to pruning, the same result: the device tests compare both with the linear scan bit for bit.)
 struct Stats8 { uint64_t nodes = 0, tris = 0; int max_sp = 0; };
 template <class T>
 static void traverse(const std::vector<uint32_t> &nodes, const std::vector<spira::HostPack4<T>> &tris, const spira::BvhFrame<T> &fr, V<T> o, V<T> d, T t_min,
