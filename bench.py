@@ -33,7 +33,8 @@ sys.path[:0] = [os.path.join(ROOT, "julia-spira_amd"), os.path.join(ROOT, "oracl
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SCENE_DESC = {"s1": "create_scene() of src/spira-metal-optimized.jl", "s2": "create_scene() of examples/julia-raytracer.jl",
-              "s3": "S1 inside a closed box", "s4": "create_scene_with_obj() of examples/julia-raytracer.jl with an 81 920-triangle procedural mesh (BVH)"}
+              "s3": "S1 inside a closed box", "s4": "create_scene_with_obj() of examples/julia-raytracer.jl with an 81 920-triangle procedural mesh (BVH)",
+              "s5": "S4's objects seen from 16 cm in front of the mesh: it fills 70 % of the frame (mesh-path stress scene)"}
 CONFIGS = {   # BASELINE.json configs[2..4]: scene, spp, depth, spp is per GPU (weak) or in total (strong)
     "c3": dict(scene="s1", spp=64, depth=8, scaling="weak", name="BASELINE configs[2]"),
     "c4": dict(scene="s3", spp=256, depth=8, scaling="strong", name="BASELINE configs[3]"),      # BASELINE.md §3 / SURVEY §8d: c4 runs on S3
@@ -51,18 +52,14 @@ def algorithmic_bytes(c, prec_bytes, kernel):
             + (3 * c["radiance_stores"] + 6 * c["radiance_rmw"]) * prec_bytes)
 
 
-KERNEL_SOURCES = ("spira_device.h", "spira_hip.hip", "spira_bvh.h", "Makefile")       # (the Makefile: the two translation units differ in compiler flags)
-
-
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) of the kernel sources: profiles/traffic_*.json carry the hash of the sources they were measured on
-    (profiles/summarize.py), and PMC figures of other sources are never attached to a bench line."""
-    import hashlib
-    h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "julia-spira_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+    """The id a library built NOW from the files on disk with the Makefile's default flags would carry (`make -s build_id`: sha256 over every file the
+    library is compiled from, the effective flag strings of its three translation units and the compiler's version line; first 16 hex digits).
+    profiles/traffic_*.json carry the id of the library they were measured on (profiles/summarize.py), and PMC figures of another build are never
+    attached to a bench line."""
+    import subprocess
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "julia-spira_amd", "csrc"), "build_id"], check=True, capture_output=True, text=True).stdout
+    return out.strip().splitlines()[-1].strip()
 
 
 def metric_string(W, H, spp, depth):
@@ -102,6 +99,17 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape, source_hash=None)
            "kernel_share_of_step": round(kms / max(c["kernel_ms"], 1e-9), 4),
            # k_path: the speculative-division launch + the exact follow-up over the waves it reported; both inside avg_launch_ms
            "waves_rendered_again": int(c.get("redone_waves", 0)), "valu": None}
+    if c.get("rays_parked", 0) and c.get("mesh_wave_trips", 0):
+        # the traversal side of a mesh scene: rays that reach the mesh's box wait on a list and are walked through the 8-wide tree in sessions
+        # (second, fat-wave launch of the pass); a trip = one memory round trip of a lane (a node visit, a triangle test, or both in Float32)
+        wms = c.get("walk_kernel_ms", 0.0)
+        rec["traversal"] = {"rays": int(c["rays_parked"]), "rays_per_sample": round(c["rays_parked"] / c["samples"], 4),
+                            "walk_launch_ms": round(wms, 4), "walk_share_of_kernel": round(wms / kms, 4) if kms > 0 else None,
+                            "Mrays_per_s": round(c["rays_parked"] / (wms * 1e-3) / 1e6, 1) if wms > 0 else None,
+                            "trips_per_ray": round(c["mesh_lane_trips"] / c["rays_parked"], 3),
+                            "walk_lane_utilisation": round(c["mesh_lane_trips"] / (64.0 * c["mesh_wave_trips"]), 4),
+                            "what": "rays = entries written to the wave-owned mesh lists (every one is walked once); walk_launch_ms = device time of the pass's second "
+                                    "launch (fat waves: sessions + the shading rounds of the paths they carry on), HIP events; Mrays_per_s = rays / walk_launch_ms"}
     tag = "%s_%s" % (scene, prec) if kernel == "wavefront" else "%s_%s_%s" % (kernel, scene, prec)
     tfile = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
     if is_headline_shape and os.path.exists(tfile):      # PMC figures of this same command (profiles/run_profile.sh)
@@ -130,8 +138,46 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape, source_hash=None)
     return rec
 
 
+def first_call_probe(prec):
+    """Run in a FRESH process (bench.py --first-call-probe f64): what a caller of the reference's only test pays — tests/bunny-test.jl:37-60 builds the mesh scene
+    and renders it ONCE at 64x64, spp 1, depth 25 (render_example's depth, examples/julia-raytracer.jl:717) through the host-array entry.  The first call holds
+    everything: device context, validation, triangle hash, the host BVH build (spira_bvh.h, on the host cores), uploads, first kernel launches, the frame back."""
+    import numpy as np
+    from spira_hip import _binding as B
+    from spira_hip import scenes
+    s = scenes.scene_s4()
+    npdt = np.float64 if prec == "f64" else np.float32
+    arrs = [np.ascontiguousarray(s[k], dtype=npdt) for k in ("spheres5", "materials8", "triangles10", "camera12")]      # (conversion is the caller's, not timed)
+    ns, nm, nt = len(arrs[0]), len(arrs[1]), len(arrs[2])
+    B.lib()
+    pp = B.make_params(64, 64, 1, 25, ns, nm, nt, seed=scenes.seed_for(5))
+    out = {"prec": prec, "triangles": nt, "host_threads": host_cpu_share()}
+    t0 = time.perf_counter()
+    B.device_count(); B.set_device(0)
+    hdr, _ = B.render(*arrs, pp, prec)
+    out["first_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    assert np.isfinite(hdr).all()
+    t0 = time.perf_counter()
+    B.render(*arrs, pp, prec)
+    out["second_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)          # the tree is cached by the hash of the triangle bytes
+    arrs[2] = arrs[2].copy(); arrs[2][0, 0] += npdt(1e-3)                        # another mesh: validation + hash + build + upload again, context warm
+    t0 = time.perf_counter()
+    B.render(*arrs, pp, prec)
+    out["new_mesh_call_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        h = B.Scene(arrs[0], arrs[1], arrs[2], prec)
+        ts.append((time.perf_counter() - t0) * 1e3)
+        h.destroy()
+    out["scene_create_ms"] = round(min(ts), 3)
+    out["scene_create_ms_all"] = [round(t, 3) for t in ts]
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--first-call-probe", default=None, choices=["f32", "f64"], help="internal: time the first call of a fresh process on the mesh scene, print JSON, exit")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps first: the first ~6 launches of a process run up to 20 %% slower (profiles/r02_s1_f64.md)")
@@ -140,7 +186,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=None, help="override the configuration's spp")
     ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--scene", default=None, choices=["s1", "s2", "s3", "s4"])
+    ap.add_argument("--scene", default=None, choices=["s1", "s2", "s3", "s4", "s5"])
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "bounce", "mega"],
                     help="wavefront = persistent hit-queue kernel (default); bounce = round-1 per-bounce launches; mega = one lane per path")
     ap.add_argument("--prec", default="f64", choices=["f32", "f64"],
@@ -151,6 +197,8 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true", help="all ranks use GPU 0 and the gloo backend (not a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    if args.first_call_probe:
+        return first_call_probe(args.first_call_probe)
 
     import numpy as np
     import torch
@@ -180,7 +228,7 @@ def main():
     depth = args.depth if args.depth is not None else cfg["depth"]
     spp_cfg = args.spp if args.spp is not None else cfg["spp"]
     spp_total = spp_cfg * world if cfg["scaling"] == "weak" else spp_cfg
-    builders = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3, "s4": scenes.scene_s4}
+    builders = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3, "s4": scenes.scene_s4, "s5": scenes.scene_s5}
     kflags = {"wavefront": B.KERNEL_WAVEFRONT, "bounce": B.KERNEL_BOUNCE, "mega": B.KERNEL_MEGA}
     seed = scenes.seed_for({"c3": 3, "c4": 4, "c5": 5}[args.config])
     tile = D.tile_params(H, world, rank)
@@ -295,12 +343,12 @@ def main():
         elif sem:
             roof = {"segments_per_sample": round(c["segments"] / c["samples"], 4)}
         elif kernel == "wavefront":
-            roof = roofline_record(c, prec, kernel, scene, (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12}.get(scene, 8), src_hash)
+            roof = roofline_record(c, prec, kernel, scene, (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12, "s5": 12}.get(scene, 8), src_hash)
         elif kernel == "bounce":     # per-bounce launches are only bracketed on request (it slows the render): one extra, profiled render
             B.render_device(*sc2, B.make_params(W, H, spp_, dep_, *counts2, flags=fl | B.FLAG_PROFILE, seed=seed, **tile),
                             o2.data_ptr(), 0, stream.cuda_stream, prec)
             torch.cuda.synchronize()
-            roof = roofline_record(B.counters(), prec, kernel, scene, (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12}.get(scene, 8), src_hash)
+            roof = roofline_record(B.counters(), prec, kernel, scene, (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12, "s5": 12}.get(scene, 8), src_hash)
             roof["note"] = "kernel time from a separate event-bracketed render (slower than the timed steps)"
         del o2
         return W * H * spp_ / adt / 1e6, adt * 1e3, roof
@@ -321,12 +369,19 @@ def main():
             v, ms, aroof = side_run(scene_name, args.kernel, ap_)
             alt = {"dtype": ap_, "value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": aroof}
         # ---- stress scene and the other kernel organisations (N=1 only; informational)
-        stress, orgs, estimators = None, None, None
+        stress, stress_mesh, orgs, estimators = None, None, None, None
         if world == 1 and not args.no_extras:
             if scene_name != "s3" and args.config != "c5":
                 v, ms, sroof = side_run("s3", args.kernel, args.prec)
                 stress = {"scene": "s3", "what": "the same frame with the scene inside a closed box: every path runs all max_depth segments (SURVEY 8d)",
                           "dtype": args.prec, "value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": sroof}
+            if (W, H) == (1920, 1080):
+                # the stress scene of the MESH path: S4's mesh filling 70 % of the frame, depth 12 — nearly every segment walks the tree
+                stress_mesh = {"scene": "s5", "what": "BASELINE configs[4]'s 81 920-triangle mesh seen from close up (70 % of the frame), spp 64, depth 12: the traversal-bound frame",
+                               "metric": metric_string(W, H, 64, 12)}
+                for pr in ("f64", "f32"):
+                    v, ms, sroof = side_run("s5", "wavefront", pr, reps=3, spp=64, dep=12, seed_=scenes.seed_for(6))
+                    stress_mesh[pr] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": sroof}
             orgs = {}
             for k in ("wavefront", "bounce", "mega"):
                 if k != args.kernel:
@@ -365,6 +420,48 @@ def main():
             e2e = (time.perf_counter() - t1) / 3
             end_to_end = {"ms": round(e2e * 1e3, 3), "value": round(samples_per_step / e2e / 1e6, 3), "unit": "Msamples/s", "d2h_bytes": int(hdr_host.nbytes),
                           "what": "spira_render_%s with host pointers: scene validation + upload, kernels, the planar frame to pageable host memory (device -> pinned staging in chunks, host threads move them on), synchronous" % args.prec}
+            # the call shape of SPIRA.jl's render(scene, camera, W, H) (src/spira-metal-optimized.jl:1453-1490 returns Matrix{RGB{Float32}}): Float32, the display image
+            # only (out_hdr = NULL), ACES + gamma: 24.9 MB to the host
+            s32 = [np.ascontiguousarray(a, dtype=np.float32) if a is not None else None for a in sc]
+            p32 = B.make_params(W, H, spp_total, depth, *counts, flags=kflags[args.kernel] | B.POST_ACES_GAMMA, seed=seed, **tile)
+            B.render(*s32, p32, "f32", want_hdr=False, want_img=True)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                _, img_host = B.render(*s32, p32, "f32", want_hdr=False, want_img=True)
+            e32 = (time.perf_counter() - t1) / 3
+            c32 = B.counters()
+            end_to_end["f32_img_only_ms"] = round(e32 * 1e3, 3)
+            end_to_end["f32_img_only_device_ms"] = round(c32["kernel_ms"], 3)
+            end_to_end["f32_img_only_d2h_bytes"] = int(img_host.nbytes)
+            if (W, H) == (1920, 1080):
+                # the call shape of the oracle script's render(world, camera, W, H) with a mesh (julia/Raytracer.jl; configs[4]): Float64 host arrays; the first call
+                # of a mesh validates, hashes and builds its tree on the host (cached afterwards by the hash of the triangle bytes)
+                m = builders["s4"]()
+                m64 = [np.ascontiguousarray(m[k], dtype=np.float64) for k in ("spheres5", "materials8", "triangles10", "camera12")]
+                pm = B.make_params(W, H, 64, 12, len(m64[0]), len(m64[1]), len(m64[2]), flags=B.POST_NONE, seed=scenes.seed_for(5))
+                t1 = time.perf_counter()
+                B.render(*m64, pm, "f64")
+                end_to_end["c5_host_arrays_first_ms"] = round((time.perf_counter() - t1) * 1e3, 3)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    B.render(*m64, pm, "f64")
+                end_to_end["c5_host_arrays_steady_ms"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+                end_to_end["c5_host_arrays_device_ms"] = round(B.counters()["kernel_ms"], 3)
+        # ---- scene build latency (N=1 only): the host BVH build + uploads of the configs[4] mesh, and the first call of a fresh process in the shape of the
+        # reference's own test (tests/bunny-test.jl:37-60: 64x64, spp 1, depth 25 — one render of a new mesh); each precision in its own fresh process
+        scene_build = None
+        if world == 1 and not args.no_extras:
+            import subprocess
+            scene_build = {"what": "fresh process per precision (bench.py --first-call-probe): first_call_ms = spira_render_* with host arrays on the 81 920-triangle scene at "
+                                   "64x64 spp 1 depth 25, everything included (context, validation, hash, host BVH build on host_threads cores, uploads, first launches, frame back); "
+                                   "second_call_ms = the same call again (tree cached); new_mesh_call_ms = another mesh in the warm context; scene_create_ms = spira_scene_create_* "
+                                   "(validate + build + upload), best of 5"}
+            for pr in ("f64", "f32"):
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--first-call-probe", pr], capture_output=True, text=True, timeout=300)
+                try:
+                    scene_build[pr] = json.loads(r.stdout.strip().splitlines()[-1])
+                except (IndexError, ValueError):
+                    scene_build[pr] = {"error": (r.stderr or r.stdout)[-400:]}
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -403,7 +500,7 @@ def main():
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": scene_name, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
-            "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "configs": other_configs, "other_precision": alt, "stress": stress,
+            "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "scene_build": scene_build, "configs": other_configs, "other_precision": alt, "stress": stress, "stress_mesh": stress_mesh,
             "organisations": orgs, "estimators": estimators, "per_rank": per_rank, "kernel_source_hash": src_hash,
         }
         print(json.dumps(result), flush=True)

@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SPIRA_ABI_VERSION 2
+#define SPIRA_ABI_VERSION 3      /* 3: spira_counters grew (rays_parked in round 3, the traversal counters and walk_kernel_ms in round 4) */
 
 /* ---- error codes ---- */
 #define SPIRA_OK            0
@@ -157,7 +157,10 @@ typedef struct spira_counters {
     uint64_t bounce_launches;    /* launches of that kernel                                 */
     uint64_t redone_waves;       /* waves whose pass was rendered a second time with the compiler's division (speculative division) */
     uint64_t rays_parked;        /* mesh scenes: rays written to (and read back from) a wave's mesh list: 3 x 16/32 bytes each way */
-} spira_counters;
+    uint64_t mesh_wave_trips;    /* mesh scenes: trips of the traversal sessions' walk loop, summed over waves (one trip = one memory round trip of every walking lane) */
+    uint64_t mesh_lane_trips;    /* ... and the lanes that took part in them: node visits + triangle tests; / (64 * mesh_wave_trips) = lane utilisation of the walk */
+    double   walk_kernel_ms;     /* mesh scenes rendered as two launches: device time of the second (fat-wave, traversal) launches; part of bounce_kernel_ms */
+} spira_counters;                /* 120 bytes */
 
 /* ---- library / device ---- */
 int         spira_abi_version(void);

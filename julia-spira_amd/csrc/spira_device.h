@@ -1002,6 +1002,7 @@ template <class T> struct RayQueue { Pack4<T> *A; Pack4<T> *B; Pack2<T> *C; };
 
 struct Stats {                       // device-side counters (one per context)
     unsigned long long segments, rays_enqueued, radiance_rmw, radiance_store, redone_waves, rays_parked;
+    unsigned long long mesh_wave_trips, mesh_lane_trips;      // traversal sessions: trips of the walk loop, and the lanes that took part in them (bvh8_step calls)
 };
 
 template <class T> struct BounceArgs {
@@ -1334,6 +1335,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                                                                                          //  renders — config 5: Float32 4.05 -> 3.88 ms, Float64 5.26 -> 5.11 ms, no spilled VGPR left in the Float64 kernels)
     Pack4<T> *mlist = a.mesh_list + 3 * (size_t)region;
     uint32_t n_rmw = 0, n_store = 0, n_seg = 0, n_enq = 0, n_park = 0;   // (n_park: entries written to the mesh list, wave-uniform)
+    uint32_t n_wtrips = 0, n_ltrips = 0;                         // trips of the traversal sessions' walk loop and the lanes walking in them (wave-uniform: scalar registers)
     uint32_t n_in = 0;                                           // packets waiting in this wave's region (rounds >= 1)
     const uint32_t n_sub_first = (a.n_first + SUB - 1) / SUB;
 
@@ -1663,10 +1665,13 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                 // ---- walk; leave the loop when enough lanes are free for a refill to pay (or, with the list exhausted, when all are done)
                 const bool more = next < mfill;
                 MESH_STAT(++dbg_rf; const unsigned long long dbg_w0 = __builtin_readcyclecounter();)
+                uint32_t n_now = (uint32_t)__popcll(__ballot(walking));
                 while (true) {
+                    ++n_wtrips; n_ltrips += n_now;
                     MESH_STAT(++dbg_ws; { const uint32_t nl = (uint32_t)__popcll(__ballot(walking)); dbg_ls += nl; if (segmented) { ++dbg_ws1; dbg_ls1 += nl; } ++dbg_h[nl <= 8 ? 0 : (nl <= 24 ? 1 : (nl <= 48 ? 2 : 3))]; })
                     if (walking && !bvh8_step<T, kLdsStack>(sc, wk, ry, o_, d_, (T)0.001, (int)ref_base, closest, prim, slot, lstack, stack, lane)) { walking = false; finished = true; }
                     const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+                    n_now = n_walk;
                     if (n_walk == 0 || (more && 64u - n_walk >= a.refill_free)) break;
                 }
                 MESH_STAT(dbg_walk += __builtin_readcyclecounter() - dbg_w0;)
@@ -1703,6 +1708,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
         }
         if (SPEC) a.redo[wid] = again ? 1u : 0u;
         if (BVH && n_park && !again && !(SPEC && a.redo_only == 2u)) atomicAdd(&a.stats->rays_parked, (unsigned long long)n_park);      // (a wave rendered again counts there)
+        if (BVH && mesh_mode != 1u && n_wtrips && !again && !(SPEC && a.redo_only == 2u)) { atomicAdd(&a.stats->mesh_wave_trips, (unsigned long long)n_wtrips); atomicAdd(&a.stats->mesh_lane_trips, (unsigned long long)n_ltrips); }
     }
 }
 

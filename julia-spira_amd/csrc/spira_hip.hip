@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -111,6 +112,9 @@ struct Ctx {
     bool have_done = false;
     std::vector<hipEvent_t> ev_pool;          // profile mode: pairs around bounce launches
     size_t ev_used = 0;
+    std::vector<hipEvent_t> ev_mid;           // mesh passes run as two launches: one event between them (-> spira_counters.walk_kernel_ms)
+    std::vector<size_t> ev_mid_end;           // ... and the ev_pool index of the event that closes that pass's bracket
+    size_t ev_mid_used = 0;
     spira_counters last{};
     bool last_valid = false, last_pending = false;
     hipStream_t last_stream = nullptr;
@@ -163,6 +167,19 @@ int get_ctx(Ctx **out) {
     *out = &c;
     return 0;
 }
+
+// SPIRA_LOG_TIMING=1: host-side phase times of a call on stderr (where a first call's milliseconds go: context, validation, tree build, uploads, launches)
+struct Lap {
+    bool on; const char *what; std::chrono::steady_clock::time_point t0, t;
+    explicit Lap(const char *w) : on(std::getenv("SPIRA_LOG_TIMING") != nullptr), what(w) { if (on) { t0 = t = std::chrono::steady_clock::now(); std::fprintf(stderr, "[spira %s]", what); } }
+    void operator()(const char *phase) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, " %s %.3f", phase, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+    ~Lap() { if (on) std::fprintf(stderr, " | total %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 
 uint32_t env_u32(const char *name, uint32_t dflt) {
     const char *s = std::getenv(name);
@@ -273,8 +290,8 @@ void scene_pointers(const SceneStore &s, spira::SceneGlobal<T> &g) {
 
 // A mesh's tree as built on the host: one build can be uploaded to several devices (spira_scene_create_multi_*).
 template <class T> struct HostBvh {
-    std::vector<uint32_t> nodes;
-    std::vector<spira::HostPack4<T>> tris;
+    spira::RawVec<uint32_t> nodes;
+    spira::RawVec<spira::HostPack4<T>> tris;
     spira::HostPack4<T> frame[3];
     uint32_t slots = 0; int depth = 0; bool built = false;
 };
@@ -299,9 +316,11 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
     const uint32_t nt_lds = use_bvh ? 0 : nt;
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t ns_b = (size_t)n_spheres * 5 * sizeof(T), nm_b = (size_t)n_materials * 8 * sizeof(T), nt_b = (size_t)nt_lds * 10 * sizeof(T);
+    Lap lap("scene_upload");
     if (int rc = s.arrays.ensure(up(ns_b) + up(nm_b) + up(nt_b) + 256)) return rc;
     s.ns = n_spheres; s.nm = n_materials; s.nt = nt;
     s.moderate = spira::scene_scale_moderate<T>(spheres5, triangles10, n_spheres, nt);
+    lap("alloc+scale");
     spira::SceneGlobal<T> g;
     scene_pointers<T>(s, g);
     if (ns_b) HIP_TRY(hipMemcpyAsync((void *)g.spheres5, spheres5, ns_b, hipMemcpyHostToDevice, st));
@@ -309,19 +328,32 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
     if (nt_b) HIP_TRY(hipMemcpyAsync((void *)g.triangles10, triangles10, nt_b, hipMemcpyHostToDevice, st));
     if (use_bvh) {
         const uint64_t h = spira::bytes_hash64(triangles10, (size_t)nt * 10 * sizeof(T));
+        lap("hash");
         if (s.bvh_hash != h || s.bvh_n != nt || s.bvh_prec != (int)sizeof(T)) {
             HostBvh<T> local;
             HostBvh<T> &hb = shared ? *shared : local;
             if (!hb.built) { if (int rc = host_bvh_build<T>(triangles10, nt, hb)) return rc; }
+            lap("bvh_build");
             if (prev_done) HIP_TRY(hipEventSynchronize(prev_done));      // nobody still reads the tree that is about to be replaced
             // (+ one record of padding each: a walk's trip loads 5 / 6 x 16 bytes from a node or a triangle alike, spira_device.h bvh8_step)
             if (int rc = s.bvh_nodes.ensure(hb.nodes.size() * sizeof(hb.nodes[0]) + 128)) return rc;
             if (int rc = s.bvh_tris.ensure(sizeof hb.frame + hb.tris.size() * sizeof(hb.tris[0]) + 128)) return rc;
-            // synchronous copies: the host vectors may die at the end of this scope
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipMemcpy(s.bvh_nodes.p, hb.nodes.data(), hb.nodes.size() * sizeof(hb.nodes[0]), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(s.bvh_tris.p, hb.frame, sizeof hb.frame, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy((char *)s.bvh_tris.p + sizeof hb.frame, hb.tris.data(), hb.tris.size() * sizeof(hb.tris[0]), hipMemcpyHostToDevice));
+            lap("hipMalloc");
+            // The three arrays go up as asynchronous copies out of the vectors pinned in place (hipHostRegister: ~11 MB for 82 k triangles in Float64;
+            // a hipMemcpy from pageable memory is staged by the runtime chunk by chunk on this thread), one wait at the end: the host vectors may die
+            // with this scope.  Pinning refused (a limit on locked memory): the plain copies.
+            const size_t nodes_b = hb.nodes.size() * sizeof(hb.nodes[0]), tris_b = hb.tris.size() * sizeof(hb.tris[0]);
+            const bool pin_n = hipHostRegister(hb.nodes.data(), nodes_b, hipHostRegisterDefault) == hipSuccess;
+            const bool pin_t = hipHostRegister(hb.tris.data(), tris_b, hipHostRegisterDefault) == hipSuccess;
+            if (!pin_n || !pin_t) (void)hipGetLastError();
+            hipError_t e1 = hipMemcpyAsync(s.bvh_nodes.p, hb.nodes.data(), nodes_b, hipMemcpyHostToDevice, st);
+            hipError_t e2 = hipMemcpyAsync(s.bvh_tris.p, hb.frame, sizeof hb.frame, hipMemcpyHostToDevice, st);
+            hipError_t e3 = hipMemcpyAsync((char *)s.bvh_tris.p + sizeof hb.frame, hb.tris.data(), tris_b, hipMemcpyHostToDevice, st);
+            hipError_t e4 = hipStreamSynchronize(st);
+            if (pin_n) (void)hipHostUnregister(hb.nodes.data());
+            if (pin_t) (void)hipHostUnregister(hb.tris.data());
+            HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
+            lap("pin+copy");
             const int depth = hb.depth;
             s.bvh_slots = hb.slots;
             s.bvh_hash = h; s.bvh_n = nt; s.bvh_prec = (int)sizeof(T); s.bvh_depth = depth;
@@ -552,9 +584,11 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     // progressive: out_hdr is the caller's running SUM (in/out), samples [sample0, sample0 + spp) are added to it
     uint32_t rows = 0;
     if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    Lap lap("render");
     if (h) { if (int rc = check_handle<T>(h)) return rc; }
     else if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, triangles10 ? p->n_triangles : 0)) return rc;
     if (int rc = validate_params(camera12, p, h ? h->store.nt : (triangles10 ? p->n_triangles : 0), &rows)) return rc;
+    lap("validate");
     if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
     if (progressive && (uint64_t)sample0 + p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "sample0 + spp exceeds 2^24");
     if (progressive && (p->flags & SPIRA_SEM_MASK) == SPIRA_SEM_METAL && sample0 > 0 && !rng_states)
@@ -566,6 +600,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     std::lock_guard<std::mutex> lock(c.mu);
     hipStream_t st = out_on_device ? (hipStream_t)user_stream : c.stream;
     if (int rc = order_after_previous(c, st)) return rc;
+    lap("context");
 
     const uint32_t W = p->width;
     const uint64_t tile_pixels = (uint64_t)rows * W;
@@ -633,9 +668,11 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     if (int rc = c.blkstats.ensure((size_t)(per_bounce ? p->max_depth + 1 : 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
     if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
 
+    lap("workspaces");
     spira::BounceArgs<T> a{};
     if (int rc = acquire_scene<T>(c, st, h, spheres5, materials8, triangles10, p, a.scene)) return rc;
     if (int rc = attach_spd<T>(c, st, p, a.scene)) return rc;
+    lap("scene");
     const bool scene_moderate = h ? h->store.moderate : c.scene.moderate;
     fill_const<T>(a.rc, camera12, p, rows, slots);
     if (!fastdiv_selfcheck(a.rc.tile_pixels, (uint32_t)batch) || !fastdiv_selfcheck(a.rc.width, a.rc.tile_pixels) ||
@@ -661,6 +698,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
         if (int rc = profile_events(c, n_prof)) return rc;
     }
     c.ev_used = 0;
+    c.ev_mid_used = 0;
 
     HIP_TRY(hipMemsetAsync(c.stats.p, 0, sizeof(spira::Stats), st));
     HIP_TRY(hipEventRecord(c.ev_start, st));
@@ -828,6 +866,13 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 if (int rc = launch_path<T>(R, dim3(G), lds_a, st, pa, spec)) return rc;
                 launches += (spec && R == 2) ? 2 : 1;      // the speculative launch and its exact follow-up
                 if (pa.mesh_mode == 1) {           // second launch: nw / k fat waves
+                    if (c.ev_mid.size() <= c.ev_mid_used) {
+                        hipEvent_t e;
+                        HIP_TRY(hipEventCreate(&e));
+                        c.ev_mid.push_back(e); c.ev_mid_end.push_back(0);
+                    }
+                    HIP_TRY(hipEventRecord(c.ev_mid[c.ev_mid_used], st));
+                    c.ev_mid_end[c.ev_mid_used++] = c.ev_used;      // (the closing event of this pass's bracket is recorded next)
                     spira::PathArgs<T> pb = pa;
                     pb.mesh_mode = 2; pb.n_first = 0;
                     const uint32_t nwb = pa.resume_nw / pa.resume_k;
@@ -878,6 +923,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c.ev_stop, st));
     HIP_TRY(hipMemcpyAsync(c.h_stats, c.stats.p, sizeof(spira::Stats), hipMemcpyDeviceToHost, st));
+    lap("enqueue");
 
     c.last = spira_counters{};
     c.last.samples = (uint64_t)p->spp * tile_pixels;
@@ -895,6 +941,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     }
     if (int rc = mark_done(c, st)) return rc;
     if (!out_on_device) HIP_TRY(hipStreamSynchronize(st));
+    lap("copy_out+sync");
     return 0;
 }
 
@@ -1353,6 +1400,15 @@ int spira_get_counters(spira_counters *out) {
         c.last.radiance_stores = c.h_stats->radiance_store;
         c.last.redone_waves = c.h_stats->redone_waves;
         c.last.rays_parked = c.h_stats->rays_parked;
+        c.last.mesh_wave_trips = c.h_stats->mesh_wave_trips;
+        c.last.mesh_lane_trips = c.h_stats->mesh_lane_trips;
+        double wms = 0;
+        for (size_t i = 0; i < c.ev_mid_used; ++i) {
+            float m = 0;
+            HIP_TRY(hipEventElapsedTime(&m, c.ev_mid[i], c.ev_pool[c.ev_mid_end[i]]));
+            wms += m;
+        }
+        c.last.walk_kernel_ms = wms;
         double bms = 0;
         for (size_t i = 0; i + 1 < c.ev_used; i += 2) {
             float m = 0;
@@ -1379,6 +1435,8 @@ void spira_shutdown(void) {
         c.redo.release(); c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
+        for (hipEvent_t e : c.ev_mid) (void)hipEventDestroy(e);
+        c.ev_mid.clear(); c.ev_mid_end.clear(); c.ev_mid_used = 0;
         (void)hipEventDestroy(c.ev_start); (void)hipEventDestroy(c.ev_stop); (void)hipEventDestroy(c.ev_done);
         c.have_done = false;
         (void)hipHostFree(c.h_stats);

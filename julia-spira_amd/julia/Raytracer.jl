@@ -85,7 +85,7 @@ const SPIRA_POST_ACES = 0x00000000     # to_acescg :370-384: clamp(aces(x), 0, 1
 
 spira_error(rc) = error("libspira_hip error $rc: " * unsafe_string(ccall((:spira_last_error, libspira), Cstring, ())))
 
-const SPIRA_ABI_VERSION = 2            # of the include/spira_hip.h these ccalls and SpiraParams were written against
+const SPIRA_ABI_VERSION = 3            # of the include/spira_hip.h these ccalls and SpiraParams were written against
 function __init__()                    # a stale library (SPIRA_HIP_LIB, an old build) would read SpiraParams with another layout
     have = ccall((:spira_abi_version, libspira), Cint, ())
     have == SPIRA_ABI_VERSION || error("$libspira has ABI version $have, this module was written for $SPIRA_ABI_VERSION")

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("SPIRA_HIP_LIB", os.path.join(CSRC, "libspira_hip.so"))   # same override as julia/SPIRA.jl
 
-ABI_VERSION = 2      # SPIRA_ABI_VERSION of the include/spira_hip.h this binding was written against (struct layouts, flag values)
+ABI_VERSION = 3      # SPIRA_ABI_VERSION of the include/spira_hip.h this binding was written against (struct layouts, flag values)
 
 # ---- flags (include/spira_hip.h) ----
 SEM_A, SEM_CPU, SEM_METAL = 0x0, 0x1, 0x2
@@ -51,7 +51,8 @@ class Params(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("rays_enqueued", C.c_uint64),
                 ("radiance_rmw", C.c_uint64), ("radiance_stores", C.c_uint64), ("passes", C.c_uint64), ("launches", C.c_uint64),
-                ("kernel_ms", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64), ("redone_waves", C.c_uint64), ("rays_parked", C.c_uint64)]
+                ("kernel_ms", C.c_double), ("bounce_kernel_ms", C.c_double), ("bounce_launches", C.c_uint64), ("redone_waves", C.c_uint64), ("rays_parked", C.c_uint64),
+                ("mesh_wave_trips", C.c_uint64), ("mesh_lane_trips", C.c_uint64), ("walk_kernel_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -3,6 +3,8 @@
 S1  create_scene() of src/spira-metal-optimized.jl:429-510 + Camera((0,1,3),(0,0,0),(0,1,0),40,16/9)
 S2  create_scene() of examples/julia-raytracer.jl:605-641 (5 spheres + 1 triangle, fov 45)
 S3  S1 enclosed in a large diffuse sphere: no path can escape, every path runs max_depth segments
+S4  create_scene_with_obj() of examples/julia-raytracer.jl:644-706 with a procedural 81 920-triangle mesh (configs[4])
+S5  S4 seen from close up: the mesh fills 70 % of the frame — the stress scene of the mesh path (the S3 of meshes)
 Each builder returns a dict(spheres5, materials8, triangles10, camera12) of float64 arrays whose
 values are exactly what the reference's constructors hold (Float32 values for S1/S3, Float64
 literals for S2); cast to the render precision at the call.
@@ -182,3 +184,12 @@ def scene_s4(level=6):
                            normalize_size=True)                           # :671-679
     cam = B.camera_lookat([0.0, 1.0, 3.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0], 45.0, 16.0 / 9.0, 1.0, prec="f64")
     return dict(spheres5=spheres5, materials8=materials8, triangles10=mesh_triangles10(v, f, 3), camera12=cam)
+
+
+def scene_s5(level=6):
+    """Mesh-dominant stress scene: the objects of S4, the camera 16 cm in front of the mesh, looking at its centre (vfov 45): the mesh
+    covers 70 % of the frame (in S4 it covers 0.7 %), so nearly every camera ray walks the tree, and every bounce off the mesh starts
+    inside the mesh's box and walks it again.  Not a reference scene: what S3 is to the sphere path, this is to G16."""
+    s = scene_s4(level)
+    s["camera12"] = B.camera_lookat([0.0, 0.1, -0.6], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0], 45.0, 16.0 / 9.0, 1.0, prec="f64")
+    return s

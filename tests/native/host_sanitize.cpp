@@ -17,11 +17,13 @@
 #include "../../julia-spira_amd/csrc/spira_validate.h"
 #include "../../include/spira_hip.h"
 
+#ifndef SPIRA_NO_ORACLE
 extern "C" {
 int oracle_render_f64(const double *, const double *, const double *, const double *, const spira_params *, double *, double *, int, uint64_t *);
 int oracle_render_f32(const float *, const float *, const float *, const float *, const spira_params *, float *, float *, int, uint64_t *);
 int oracle_render_variant_f32(const float *, const float *, const float *, const spira_params *, float *, float *, int, uint64_t *);
 }
+#endif
 
 static int g_fail = 0;
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
@@ -60,7 +62,7 @@ template <class T> static uint32_t bits_of(T w) {
 // nodes and triangles up to pruning, the same result: the device tests compare both with the linear scan bit for bit.)
 struct Stats8 { uint64_t nodes = 0, tris = 0; int max_sp = 0; };
 template <class T>
-static void traverse(const std::vector<uint32_t> &nodes, const std::vector<spira::HostPack4<T>> &tris, const spira::BvhFrame<T> &fr, V<T> o, V<T> d, T t_min,
+static void traverse(const spira::RawVec<uint32_t> &nodes, const spira::RawVec<spira::HostPack4<T>> &tris, const spira::BvhFrame<T> &fr, V<T> o, V<T> d, T t_min,
                      T &closest, int &prim, Stats8 &st) {
     const V<T> inv = {(T)1 / d.x, (T)1 / d.y, (T)1 / d.z};
     T te;
@@ -124,12 +126,12 @@ static void traverse(const std::vector<uint32_t> &nodes, const std::vector<spira
 }
 
 template <class T>
-static void check_mesh(const char *name, const std::vector<T> &t10, uint32_t n_rays, uint32_t seed) {
+static void check_mesh(const char *name, const std::vector<T> &t10, uint32_t n_rays, uint32_t seed, unsigned n_threads = 0) {
     const uint32_t n = (uint32_t)(t10.size() / 10);
-    std::vector<uint32_t> nodes;
-    std::vector<spira::HostPack4<T>> tris;
+    spira::RawVec<uint32_t> nodes;
+    spira::RawVec<spira::HostPack4<T>> tris;
     spira::BvhFrame<T> fr{};
-    const bool ok = spira::bvh_build<T>(t10.data(), n, nodes, tris, fr);
+    const bool ok = spira::bvh_build<T>(t10.data(), n, nodes, tris, fr, n_threads);
     CHECK(ok);
     if (!ok) return;
     CHECK(tris.size() == 3 * (size_t)n && nodes.size() == (size_t)fr.n_slots * spira::kBvhNodeDwords && fr.n_slots >= 1 && fr.depth < spira::kBvhStack - 2);
@@ -209,6 +211,29 @@ template <class T> static void meshes() {
     }
 }
 
+// The build runs on a pool of host threads (spira_bvh.h: chunk-parallel passes near the root, a shared queue of subtrees, level-parallel collapse):
+// whatever the number of threads, the node and triangle arrays must come out byte for byte the same — and equal the linear scan.
+template <class T> static void determinism(uint32_t n, uint32_t seed) {
+    const std::vector<T> t10 = soup<T>(n, seed, 0.05);
+    spira::RawVec<uint32_t> nodes1;
+    spira::RawVec<spira::HostPack4<T>> tris1;
+    spira::BvhFrame<T> fr1{};
+    CHECK(spira::bvh_build<T>(t10.data(), n, nodes1, tris1, fr1, 1));
+    for (unsigned nt : {2u, 3u, 8u, 13u}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            spira::RawVec<uint32_t> nodes;
+            spira::RawVec<spira::HostPack4<T>> tris;
+            spira::BvhFrame<T> fr{};
+            CHECK(spira::bvh_build<T>(t10.data(), n, nodes, tris, fr, nt));
+            CHECK(nodes.size() == nodes1.size() && tris.size() == tris1.size() && fr.n_slots == fr1.n_slots && fr.depth == fr1.depth);
+            CHECK(nodes.size() == nodes1.size() && std::memcmp(nodes.data(), nodes1.data(), nodes.size() * sizeof(uint32_t)) == 0);
+            CHECK(tris.size() == tris1.size() && std::memcmp(tris.data(), tris1.data(), tris.size() * sizeof(tris[0])) == 0);
+            CHECK(std::memcmp(&fr, &fr1, sizeof fr) == 0);
+        }
+    }
+    std::printf("determinism %-6s n=%-6u slots=%-6u depth=%d: 1 == 2 == 3 == 8 == 13 threads\n", sizeof(T) == 4 ? "f32" : "f64", n, fr1.n_slots, fr1.depth);
+}
+
 static void fastdiv_checks() {
     std::mt19937 rng(7);
     const uint32_t ds[] = {1, 2, 3, 5, 7, 8, 64, 1000, 1920, 2073600, 132710400, 0x7FFFFFFF, 0x80000000u, 0xFFFFFFFFu};
@@ -253,13 +278,14 @@ static void validation_checks() {
     t10[4] = NAN; CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == SPIRA_E_INVALID);
     t10[4] = 0; t10[9] = 0; CHECK(spira::scene_arrays_check<double>(nullptr, m8d, t10, 0, 1, 1, &msg) == SPIRA_E_INVALID);
     CHECK(spira::scene_arrays_check<double>(nullptr, nullptr, nullptr, 0, 1, 0, &msg) == SPIRA_E_INVALID);
-    std::vector<uint32_t> nodes;
-    std::vector<spira::HostPack4<float>> tris;
+    spira::RawVec<uint32_t> nodes;
+    spira::RawVec<spira::HostPack4<float>> tris;
     spira::BvhFrame<float> fr{};
     CHECK(!spira::bvh_build<float>(nullptr, 0, nodes, tris, fr));                                 // empty
     CHECK(!spira::bvh_build<float>(nullptr, (1u << 24) + 1, nodes, tris, fr));                    // over the 2^24 limit: rejected before any read
 }
 
+#ifndef SPIRA_NO_ORACLE
 static void oracle_checks() {   // the checker itself under ASan/UBSan: S2-like scene, all estimators, extensions, tilings, row orders
     const double sph[25] = {0, -100.5, -1, 100, 1, 0, 0, -1, 0.5, 2, 1, 0, -1, 0.5, 3, -1, 0, -1, 0.5, 4, 0, 2, 0, 0.5, 5};
     const double mat[48] = {0.8, 0.8, 0.2, 0, 0, 0, 0, 1, 0.8, 0.2, 0.2, 0, 0, 0, 0, 1, 0.8, 0.6, 0.2, 0, 0, 0, 0.8, 0.3, 0.9, 0.9, 0.9, 0, 0, 0, 0, -1.5,
@@ -286,13 +312,28 @@ static void oracle_checks() {   // the checker itself under ASan/UBSan: S2-like 
     }
     for (float v : hf) CHECK(std::isfinite(v));
 }
+#endif
 
-int main() {
+int main(int argc, char **argv) {
+    // all three regimes of the parallel build: > 16 384 items (chunk-parallel splits), the shared queue, the plain recursion; small meshes with a forced pool
+    determinism<float>(40000, 21);
+    determinism<double>(40000, 22);
+    determinism<float>(700, 23);
+    determinism<double>(5, 24);
+    if (argc > 1 && std::strcmp(argv[1], "determinism") == 0) {      // (the ThreadSanitizer build runs this part only)
+        if (g_fail) { std::fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
+        std::printf("host sanitize harness: all checks passed\n");
+        return 0;
+    }
+    check_mesh<float>("big soup, 8 threads", soup<float>(40000, 25, 0.05), 150, 18, 8);
+    check_mesh<double>("big soup, 3 threads", soup<double>(40000, 26, 0.05), 150, 19, 3);
     meshes<float>();
     meshes<double>();
     fastdiv_checks();
     validation_checks();
+#ifndef SPIRA_NO_ORACLE
     oracle_checks();
+#endif
     if (g_fail) { std::fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
     std::printf("host sanitize harness: all checks passed\n");
     return 0;

@@ -22,12 +22,40 @@ def test_exports_match_header(binding):
     for name in sorted(declared):
         assert hasattr(lib, name), "libspira_hip.so does not export %s" % name
     assert declared == set(binding.EXPORTS)
-    assert lib.spira_abi_version() == 2
+    assert lib.spira_abi_version() == 3
 
 
 def test_struct_sizes(binding):
     assert C.sizeof(binding.Params) == 64
-    assert C.sizeof(binding.Counters) == 12 * 8
+    assert C.sizeof(binding.Counters) == 15 * 8
+
+
+def _header_struct_fields(name):
+    """(type, field) pairs of `typedef struct <name> { ... } <name>;` in include/spira_hip.h, in declaration order."""
+    hdr = open(os.path.join(ROOT, "include", "spira_hip.h")).read()
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.split(None, 1)
+        out += [(ctype, n.strip()) for n in names.split(",")]
+    return out
+
+
+def test_ctypes_structs_mirror_the_header_field_by_field(binding):
+    """a struct that grows must bump SPIRA_ABI_VERSION, and the ctypes mirror must follow the header's fields in order,
+    type and size — spira_get_counters writes sizeof(spira_counters) bytes into the caller's buffer."""
+    ctype_of = {"uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "double": C.c_double}
+    for struct, mirror in (("spira_params", binding.Params), ("spira_counters", binding.Counters)):
+        fields = _header_struct_fields(struct)
+        assert [n for _, n in fields] == [n for n, _ in mirror._fields_], struct
+        assert [ctype_of[t] for t, _ in fields] == [t for _, t in mirror._fields_], struct
+        assert C.sizeof(mirror) == sum(C.sizeof(ctype_of[t]) for t, _ in fields), struct      # no padding either side
+    import oracle_py
+    assert [n for _, n in _header_struct_fields("spira_params")] == [n for n, _ in oracle_py.SpiraParams._fields_]
 
 
 def test_library_is_gfx950_only():
@@ -313,9 +341,9 @@ def test_julia_export_lists_cover_the_reference_and_the_python_twins():
 def test_both_julia_modules_refuse_a_library_of_another_abi_version():
     for fname in ("SPIRA.jl", "Raytracer.jl"):
         src = open(os.path.join(ROOT, "julia-spira_amd", "julia", fname)).read()
-        assert "const SPIRA_ABI_VERSION = 2" in src and "function __init__()" in src and "ccall((:spira_abi_version, libspira), Cint, ())" in src, fname
+        assert "const SPIRA_ABI_VERSION = 3" in src and "function __init__()" in src and "ccall((:spira_abi_version, libspira), Cint, ())" in src, fname
     from spira_hip import _binding
-    assert _binding.ABI_VERSION == 2
+    assert _binding.ABI_VERSION == 3
 
 
 def test_flatten_world_gives_one_material_row_per_distinct_material(binding):
