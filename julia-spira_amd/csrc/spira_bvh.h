@@ -406,7 +406,8 @@ template <class T> struct Bvh8Build {
 // Builds the structure over n triangles (caller's triangles10 layout).  Outputs: nodes (kBvhNodeDwords per slot, slot 0 = root),
 // tris (3 packets per triangle, node order), frame.  Returns false if a limit is hit.  n_threads = 0: build_threads().
 template <class T>
-bool bvh_build(const T *triangles10, uint32_t n, RawVec<uint32_t> &nodes, RawVec<HostPack4<T>> &tris, BvhFrame<T> &frame, unsigned n_threads = 0) {
+bool bvh_build(const T *triangles10, uint32_t n, RawVec<uint32_t> &nodes, RawVec<HostPack4<T>> &tris, BvhFrame<T> &frame, unsigned n_threads = 0,
+               RawVec<HostPack4<float>> *tris32 = nullptr) {
     if (n == 0 || n > kBvhMaxTris) return false;
     HostPool pool(n_threads ? n_threads : (n < 4096 ? 1u : build_threads()));      // (a small mesh is built faster than threads are started)
     using B8 = Bvh8Build<T>;
@@ -619,14 +620,32 @@ bool bvh_build(const T *triangles10, uint32_t n, RawVec<uint32_t> &nodes, RawVec
     frame.n_slots = (uint32_t)(nodes.size() / kBvhNodeDwords);
     frame.depth = depth;
     tris.resize(3 * (size_t)n);
+    if (tris32) tris32->resize(3 * (size_t)n);
     pool.run(n_chunks, [&](size_t j) {
         const uint32_t i1 = std::min(n, ((uint32_t)j + 1) * kChunk);
         for (uint32_t i = (uint32_t)j * kChunk; i < i1; ++i) {
             const uint32_t oi = b.items[order[i]].idx;
             const T *t = triangles10 + 10 * (size_t)oi;
+            const T e1[3] = {(T)(t[3] - t[0]), (T)(t[4] - t[1]), (T)(t[5] - t[2])};      // edge1 = v1 - v0, :149
+            const T e2[3] = {(T)(t[6] - t[0]), (T)(t[7] - t[1]), (T)(t[8] - t[2])};      // edge2 = v2 - v0, :150
             tris[3 * (size_t)i + 0] = {t[0], t[1], t[2], bits_to_real<T>(oi)};
-            tris[3 * (size_t)i + 1] = {(T)(t[3] - t[0]), (T)(t[4] - t[1]), (T)(t[5] - t[2]), bits_to_real<T>((uint32_t)t[9] - 1u)};   // edge1 = v1 - v0, :149
-            tris[3 * (size_t)i + 2] = {(T)(t[6] - t[0]), (T)(t[7] - t[1]), (T)(t[8] - t[2]), (T)0};                                // edge2 = v2 - v0, :150
+            tris[3 * (size_t)i + 1] = {e1[0], e1[1], e1[2], bits_to_real<T>((uint32_t)t[9] - 1u)};
+            tris[3 * (size_t)i + 2] = {e2[0], e2[1], e2[2], (T)0};
+            if (tris32) {
+                // The Float32 screening record of a Float64 walk (spira_device.h, tri_maybe_f32): the same triangle in the normalised frame, rounded to
+                // Float32 — v0 with an absolute error of 2^-24 of a coordinate (|coordinate| <= ~0.55), the edges with a relative one — and
+                // L >= max(|e1|_inf, |e2|_inf), the scale of the screen's error bounds.
+                float v[3], f1[3], f2[3], L = 0.0f;
+                for (int k = 0; k < 3; ++k) {
+                    v[k] = (float)(((double)t[k] - centre[k]) * scale);
+                    f1[k] = (float)((double)e1[k] * scale); f2[k] = (float)((double)e2[k] * scale);
+                    L = std::max(L, std::max(std::fabs(f1[k]), std::fabs(f2[k])));
+                }
+                L = std::nextafter(L, std::numeric_limits<float>::infinity());
+                (*tris32)[3 * (size_t)i + 0] = {v[0], v[1], v[2], bits_float(oi)};
+                (*tris32)[3 * (size_t)i + 1] = {f1[0], f1[1], f1[2], L};
+                (*tris32)[3 * (size_t)i + 2] = {f2[0], f2[1], f2[2], 0.0f};
+            }
         }
     });
     return true;

@@ -229,6 +229,7 @@ template <class T> struct SceneLds {
     // large meshes: 8-wide quantised BVH in global memory (spira_bvh.h), L2 / Infinity-Cache resident
     const uint4 *bvh_nodes;     // 5 x uint4 per node slot
     const Pack4<T> *bvh_tris;
+    const uint4 *bvh_tris32;    // Float64 scenes: the Float32 screening records of the walk (3 x uint4 per triangle, normalised frame), else NULL
     uint32_t n_bvh_tris;
     const Pack4<T> *bvh_root;   // LDS: {min}, {max} of the whole mesh's padded box (caller's coordinates, render precision) — a ray that misses
                                 // it never touches the tree — and {centre, scale} of the normalised frame the node boxes live in
@@ -245,6 +246,7 @@ template <class T> struct SceneGlobal {     // flat arrays exactly as passed thr
     uint32_t n_spheres, n_materials, n_triangles;
     const uint4 *bvh_nodes;         // spira_bvh.h: 5 x uint4 per node slot, slot 0 = root
     const Pack4<T> *bvh_tris;       // 3 packets per triangle, node order
+    const uint4 *bvh_tris32;        // Float64: 3 x uint4 per triangle, the same order — {v0, index} {e1, L} {e2, 0} in Float32, normalised frame (spira_bvh.h)
     const Pack4<T> *bvh_frame;      // 3 packets: root box min, max (caller's coordinates), {centre, scale}
     uint32_t n_bvh_tris;
     uint32_t bvh_slots;             // node slots in bvh_nodes
@@ -316,7 +318,7 @@ __device__ __forceinline__ SceneLds<T> stage_scene(const SceneGlobal<T> &g, unsi
     SceneLds<T> sc;
     sc.sph = sph; sc.tri = tri; sc.mat = mat; sc.smat = smat; sc.tmat = tmat;
     sc.n_spheres = g.n_spheres; sc.n_triangles = g.n_triangles;
-    sc.bvh_nodes = g.bvh_nodes; sc.bvh_tris = g.bvh_tris; sc.n_bvh_tris = g.n_bvh_tris;
+    sc.bvh_nodes = g.bvh_nodes; sc.bvh_tris = g.bvh_tris; sc.bvh_tris32 = g.bvh_tris32; sc.n_bvh_tris = g.n_bvh_tris;
     sc.spd = spd;
     sc.bvh_root = root;
     return sc;
@@ -406,6 +408,8 @@ struct Bvh8Ray {
     float ix, iy, iz;        // 1 / d, magnitude clamped to 2^40 (a slab the ray runs parallel to: inside -> (-huge, huge), outside -> beyond every exit)
     uint32_t oct;            // bit k: d_k < 0
     float best;              // closest hit so far as a distance from (ox, oy, oz), normalised units, rounded up
+    float tmin;              // Float64 walks (their Float32 screen): t_min as a distance from (ox, oy, oz), normalised units, rounded down
+    float amin;              // ... and the scan's |a| >= 1e-8 (:157) in the normalised frame's units, rounded up: 1e-8 scale^2
 };
 template <class T> struct Bvh8Walk {      // one lane's traversal state
     uint32_t G;              // current node group: child_base << 8 | hit children still to visit, bit (slot ^ oct): ascending = front to back
@@ -413,7 +417,9 @@ template <class T> struct Bvh8Walk {      // one lane's traversal state
     uint32_t rank;           // the node's leaf ranks (4 bits per slot): the triangle of leaf slot s is tri_base + rank_s
     int sp;
     T t0;                    // ray parameter of (ox, oy, oz)
+    uint32_t c0, c1, c2, c3, nc;   // Float64 walk: the triangles its Float32 screen could not reject (newest first), nc of them: their exact tests wait for a batch
 };
+constexpr uint32_t kBvhCand = 4;
 
 __device__ __forceinline__ float bvh8_rcp(float dx, bool neg) {
     const float a = __builtin_fmaxf(__builtin_fabsf(dx), 9.094947017729282e-13f);     // 2^-40
@@ -437,6 +443,7 @@ __device__ __forceinline__ bool bvh8_enter(const SceneLds<T> &sc, Vec<T> o, Vec<
     r.oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
     r.ix = bvh8_rcp(dx, nx); r.iy = bvh8_rcp(dy, ny); r.iz = bvh8_rcp(dz, nz);
     r.best = bvh8_best((float)((closest - te) * fr.w));
+    r.tmin = 0.0f; r.amin = 0.0f;      // (set by bvh8_begin)
     return true;
 }
 
@@ -491,8 +498,86 @@ __device__ __forceinline__ void bvh8_tri_words(const uint4 w0, const uint4 w1, c
 }
 
 // start at the root: a group holding only slot 0 (child_base 0, bit 0 ^ oct: slot = bit ^ oct = 0)
-template <class T> __device__ __forceinline__ void bvh8_begin(Bvh8Walk<T> &w, const Bvh8Ray &r, T t0) {
-    w.G = 1u << r.oct; w.tw = 0; w.rank = 0; w.sp = 0; w.t0 = t0;
+template <class T> __device__ __forceinline__ void bvh8_begin(Bvh8Walk<T> &w, Bvh8Ray &r, T t0, T t_min, T scale) {
+    w.G = 1u << r.oct; w.tw = 0; w.rank = 0; w.sp = 0; w.t0 = t0; w.c0 = w.c1 = w.c2 = w.c3 = 0; w.nc = 0;
+    // t_min seen from the entry point, rounded DOWN (a smaller bound rejects less): one part in 2^20 and a denormal-proof 2^-60 below the converted value
+    const float tm = (float)((t_min - t0) * scale);
+    r.tmin = tm - __builtin_fabsf(tm) * 9.5367431640625e-7f - 8.673617379884035e-19f;
+    const float sc32 = (float)scale;                     // (a scale beyond Float32: amin = Inf, no triangle is ever "certain"; below it: 0, every |a| above its error bound is)
+    r.amin = ((1.0000001e-8f * sc32) * sc32) * 1.00000095367431640625f;
+}
+
+// ---- Float64 walks screen their triangles in Float32: BUILT, VERIFIED, MEASURED SLOWER, NOT THE DEFAULT (-DSPIRA_BVH_SCREEN) ----
+// Round 4, same box, alternating libraries, 1080p spp 64 depth 12, Float64: mesh stress scene S5 67.4 -> 71.1 ms per frame (+5.5 %), BASELINE configs[4]
+// 5.78 -> 5.91 ms (+2 %), although a ray needs 14 % fewer trips (17.7 -> 15.2, the Float32 walk's count).  Why: a trip is bound by its memory round trip, not by
+// its arithmetic (5 100 .. 5 450 cycles per wave-trip whichever arms run, profiles/experiments/mesh_stats.py), and the deferred exact tests are round trips
+// of their own (one per group of finished lanes, every ~5.5 trips).  The first form — exact test in the lane's next trip — lost 8 %: with 64 lanes some lane
+// holds a candidate in 92 % of the trips, so the wave ran the Float64 arm almost every trip anyway.  Kept as an experiment build with its contract test.
+// A Float64 triangle record is 96 bytes and its test ~75 Float64 instructions; four out of five tests of a walk reject.  So a Float64 walk tests the
+// Float32 copy of the triangle (48 bytes, the record a Float32 walk loads; normalised frame, ray from its entry point into the mesh's box) with every
+// comparison widened by a bound on what Float32 rounding can have done to its two sides.  A triangle that MAY pass becomes a candidate of the ray, and the
+// candidates are put through the scan's own Float64 test, which alone decides (so the result is exactly the linear scan's, as before) — not in the walk's
+// loop, where one lane of 64 with a candidate would make the whole wave run the Float64 arm (measured: 92 % of the trips, S5 +8 % frame time), but in
+// batches: when the lanes that finished their walk hand over their results, or when a lane's list is full.  A triangle that passes FOR SURE bounds the hit
+// distance from above, and the walk prunes with that bound.
+// "May pass" must hold for every triangle the exact test accepts.  With u = 2^-24, all inputs rounded once from their Float64 values (|coordinates| <=
+// ~0.55 in the normalised frame, |d| = 1), Le = max(|e1|_inf, |e2|_inf) (stored with the record, rounded up), sm = |sv|_inf, plain left-to-right arithmetic:
+//   |d(sv)|_inf <= u (|P| + |v0| + |sv|)_inf <= 2.2 u + u sm        |d(h)|_inf <= 8 u Le  (h = d x e2, |h|_inf <= 2 Le)
+//   |d(a)|  <= 48 u Le^2                                            (a = e1 . h)
+//   |d(nu)|, |d(nv)| <= u Le (19.2 + 42 sm)                         (nu = sv . h;  q = sv x e1, |d(q)|_inf <= u Le (6.4 + 6 sm);  nv = d . q)
+//   |d(nt)| <= u Le^2 (19.2 + 42 sm)                                (nt = e2 . q)
+// used below as EL = (32 + 64 sm) u Le, ET = EL Le, EA = 64 u Le^2 (margins of 1.3 .. 1.6 over the bounds; the sums and products of the comparisons
+// themselves add a few u of their own, inside those margins).  The exact test's conditions in these terms, s = sign(a):
+//   u >= 0: s nu >= 0;  v >= 0: s nv >= 0;  u + v <= 1: s (nu + nv) <= |a|;  t in [t_min, closest]: tmin |a| <= s nt <= best |a|
+// (u <= 1 follows from v >= 0 and u + v <= 1).  |a| <= EA: the sign is not known, the triangle may pass.  The Float64 evaluation of the exact test
+// deviates from these real-number conditions by parts in 2^53 of the same terms: eight orders of magnitude inside the bounds.
+// Returns 0: the exact test certainly rejects; 1: it may accept; 2: it certainly accepts unless a closer hit is known — then t_hi bounds the hit distance
+// (normalised units from the entry point) from above.  Class 2 needs every condition to hold by the same margins the other way round, |a| >= 1e-8 (:157) included.
+// tests/native/tri_screen.hip draws 2^30 ray / triangle pairs (rays through edges and vertices, grazing rays, slivers, far-away meshes): no triangle the
+// exact test accepts is rejected, every class-2 triangle is accepted by the exact test at a distance below its bound.
+__device__ __forceinline__ int tri_screen_f32(const uint4 u0, const uint4 u1, const uint4 u2, const Bvh8Ray &r, float dx, float dy, float dz, float &t_hi) {
+    const float e1x = __uint_as_float(u1.x), e1y = __uint_as_float(u1.y), e1z = __uint_as_float(u1.z), Le = __uint_as_float(u1.w);
+    const float e2x = __uint_as_float(u2.x), e2y = __uint_as_float(u2.y), e2z = __uint_as_float(u2.z);
+    const float svx = r.ox - __uint_as_float(u0.x), svy = r.oy - __uint_as_float(u0.y), svz = r.oz - __uint_as_float(u0.z);
+    const float hx = dy * e2z - dz * e2y, hy = dz * e2x - dx * e2z, hz = dx * e2y - dy * e2x;
+    const float a = e1x * hx + e1y * hy + e1z * hz;
+    const float nu = svx * hx + svy * hy + svz * hz;
+    const float qx = svy * e1z - svz * e1y, qy = svz * e1x - svx * e1z, qz = svx * e1y - svy * e1x;
+    const float nv = dx * qx + dy * qy + dz * qz;
+    const float nt = e2x * qx + e2y * qy + e2z * qz;
+    const float sm = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(svx), __builtin_fabsf(svy)), __builtin_fabsf(svz));
+    const float EL = (1.9073486328125e-6f + 3.814697265625e-6f * sm) * Le;        // (32 + 64 sm) 2^-24 Le
+    const float ET = EL * Le, EA = (3.814697265625e-6f * Le) * Le;                // 64 2^-24 Le^2
+    const float aa = __builtin_fabsf(a);
+    t_hi = 0.0f;
+    if (!(aa > EA)) return 1;                                                      // (also a NaN from an overflow: the exact test decides)
+    const bool neg = a < 0.0f;
+    const float su = neg ? -nu : nu, sv_ = neg ? -nv : nv, st = neg ? -nt : nt;
+    const float suv = su + sv_, EUV = 2.0f * EL + EA, tlo = r.tmin * aa, EM = ET + __builtin_fabsf(r.tmin) * EA;
+    if (su < -EL || sv_ < -EL || suv > aa + EUV || st > r.best * aa + (ET + r.best * EA) || st < tlo - EM) return 0;
+    // inside by the same margins, beyond t_min by them, the determinant clear of 1e-8: a hit for sure (if nothing closer is known)
+    const float alo = aa - EA;
+    if (su > EL && sv_ > EL && suv < aa - EUV && st > tlo + EM + 1.9073486328125e-6f * __builtin_fabsf(tlo) && alo > r.amin) {
+        t_hi = (((st + ET) * 1.0000002384185791015625f) * __builtin_amdgcn_rcpf(alo * 0.99999988079071044921875f)) * 1.00000095367431640625f;
+        return 2;
+    }
+    return 1;
+}
+
+// Float64 walks: the exact (scan's own, Float64) test of the newest candidate of this lane's list.  One memory round trip (the 96-byte record).
+template <class T>
+__device__ __forceinline__ void bvh8_resolve_one(const SceneLds<T> &sc, Bvh8Walk<T> &w, Bvh8Ray &r, Vec<T> o, Vec<T> d, T t_min, int base, T &closest, int &prim, uint32_t &slot) {
+    const uint32_t ti = w.c0;
+    w.c0 = w.c1; w.c1 = w.c2; w.c2 = w.c3; --w.nc;
+    const Pack4<T> v0 = sc.bvh_tris[3 * (size_t)ti], e1 = sc.bvh_tris[3 * (size_t)ti + 1], e2 = sc.bvh_tris[3 * (size_t)ti + 2];
+    T t;
+    if (triangle_test<T>(v0, e1, e2, o, d, t_min, closest, t)) {
+        const int p = base + (int)Bits<T>::to_u32(v0.w);
+        if (t < closest || p > prim) {                                // t == closest: the later object wins
+            closest = t; prim = p; slot = ti;
+            r.best = __builtin_fminf(r.best, bvh8_best((float)((t - w.t0) * sc.bvh_root[2].w)));
+        }
+    }
 }
 
 // One trip of a lane's walk = ONE memory round trip: a lane with triangles pending tests the next one (render precision, caller's
@@ -513,6 +598,63 @@ __device__ __forceinline__ bool bvh8_step(const SceneLds<T> &sc, Bvh8Walk<T> &w,
 #else
     constexpr bool kDual = !kWide;
 #endif
+#ifdef SPIRA_BVH_SCREEN
+    constexpr bool kScreen = kWide;          // experiment build (see tri_screen_f32): measured 2 .. 6 % SLOWER than testing every triangle in Float64 where it is met
+#else
+    constexpr bool kScreen = false;
+#endif
+    if constexpr (kScreen) {
+        // Float64: the Float32 walk's trip (a node's last pending triangle AND the next node visit in one round trip, 5 + 3 loads), the triangle SCREENED in
+        // Float32 (tri_screen_f32): a triangle that may be hit joins the lane's candidate list; its Float64 test is run by bvh8_resolve_one(), in batches.
+        const bool do_tri = (w.tw >> 24) != 0;
+        uint32_t ti = 0;
+        const uint4 *pt = sc.bvh_tris32;
+        if (do_tri) {
+            const uint32_t s_ = (uint32_t)__builtin_ctz(w.tw >> 24);
+            ti = (w.tw & 0x00FFFFFFu) + ((w.rank >> (4u * s_)) & 15u);
+            w.tw &= ~(0x01000000u << s_);
+            pt = sc.bvh_tris32 + 3 * (size_t)ti;
+        }
+        bool do_node = (w.tw >> 24) == 0;
+        if (do_node && !(w.G & 0xFFu)) {
+            if (w.sp == 0) do_node = false;
+            else { --w.sp; w.G = (KL > 0 && w.sp < KL) ? lds_stack[w.sp * 64 + lane] : stack[w.sp - KL]; }
+        }
+        const uint4 *pn = sc.bvh_nodes;
+        if (do_node) {
+            const uint32_t pos = (uint32_t)__builtin_ctz(w.G);
+            const uint32_t idx = (w.G >> 8) + (pos ^ r.oct);
+            w.G &= w.G - 1u;
+            if (w.G & 0xFFu) {
+                if (KL > 0 && w.sp < KL) lds_stack[w.sp * 64 + lane] = w.G; else stack[w.sp - KL] = w.G;
+                ++w.sp;
+            }
+            pn = sc.bvh_nodes + 5 * (size_t)idx;
+        }
+        const uint4 n0 = pn[0], n1 = pn[1], n2 = pn[2], n3 = pn[3], n4 = pn[4];
+        const uint4 u0 = pt[0], u1 = pt[1], u2 = pt[2];
+        asm volatile("" :: "v"(n0.x), "v"(n0.y), "v"(n0.z), "v"(n0.w), "v"(n1.x), "v"(n1.y), "v"(n1.z), "v"(n1.w), "v"(n2.x), "v"(n2.y), "v"(n2.z), "v"(n2.w) : "memory");
+        asm volatile("" :: "v"(n3.x), "v"(n3.y), "v"(n3.z), "v"(n3.w), "v"(n4.x), "v"(n4.y), "v"(n4.z), "v"(n4.w) : "memory");
+        asm volatile("" :: "v"(u0.x), "v"(u0.y), "v"(u0.z), "v"(u0.w), "v"(u1.x), "v"(u1.y), "v"(u1.z), "v"(u1.w), "v"(u2.x), "v"(u2.y), "v"(u2.z), "v"(u2.w) : "memory");
+        if (do_tri) {
+            float t_hi;
+            const int cls = tri_screen_f32(u0, u1, u2, r, (float)d.x, (float)d.y, (float)d.z, t_hi);
+            if (cls != 0) {
+                // a full list is emptied on the spot (rare: a ray grazing many triangles): this lane's candidates all go through the exact test now
+                if (__builtin_expect(w.nc == kBvhCand, 0)) { while (w.nc) bvh8_resolve_one<T>(sc, w, r, o, d, t_min, base, closest, prim, slot); }
+                w.c3 = w.c2; w.c2 = w.c1; w.c1 = w.c0; w.c0 = ti; ++w.nc;
+                if (cls == 2) r.best = __builtin_fminf(r.best, t_hi);
+            }
+        }
+        if (do_node) {
+            uint32_t ih, lh;
+            bvh8_node(n0, n1, n2, n3, n4, r, ih, lh);
+            w.G = (n1.x << 8) | ih;
+            w.tw = n1.y | (lh << 24);
+            w.rank = n1.z;
+        }
+        return (w.tw >> 24) != 0 || (w.G & 0xFFu) != 0 || w.sp > 0;
+    }
     if constexpr (kDual) {
         const bool do_tri = (w.tw >> 24) != 0;
         uint32_t ti = 0;
@@ -633,6 +775,62 @@ __device__ __forceinline__ bool bvh8_step(const SceneLds<T> &sc, Bvh8Walk<T> &w,
     return true;
 }
 
+// The screened trip of a traversal SESSION's Float64 walk (k_path): the same trip as the kScreen branch of bvh8_step, but the lane carries nothing of its ray
+// in Float64 — direction in Float32, origin = the entry point inside Bvh8Ray — because the Float64 tests of its candidates run outside the walk's loop,
+// from the parked entry re-read there.  Returns 0: the walk is over; 1: go on; 2: the candidate list is full (nothing was done: the caller empties it).
+enum : int { kWalkDone = 0, kWalkOn = 1, kWalkFull = 2 };
+template <int KL>
+__device__ __forceinline__ int bvh8_step_screened(const uint4 *nodes, const uint4 *tris32, Bvh8Walk<double> &w, Bvh8Ray &r, float dx, float dy, float dz,
+                                                  uint32_t *lds_stack, uint32_t *stack, uint32_t lane) {
+    if (__builtin_expect(w.nc == kBvhCand, 0)) return kWalkFull;
+    const bool do_tri = (w.tw >> 24) != 0;
+    uint32_t ti = 0;
+    const uint4 *pt = tris32;
+    if (do_tri) {
+        const uint32_t s_ = (uint32_t)__builtin_ctz(w.tw >> 24);
+        ti = (w.tw & 0x00FFFFFFu) + ((w.rank >> (4u * s_)) & 15u);
+        w.tw &= ~(0x01000000u << s_);
+        pt = tris32 + 3 * (size_t)ti;
+    }
+    bool do_node = (w.tw >> 24) == 0;
+    if (do_node && !(w.G & 0xFFu)) {
+        if (w.sp == 0) do_node = false;
+        else { --w.sp; w.G = (KL > 0 && w.sp < KL) ? lds_stack[w.sp * 64 + lane] : stack[w.sp - KL]; }
+    }
+    const uint4 *pn = nodes;
+    if (do_node) {
+        const uint32_t pos = (uint32_t)__builtin_ctz(w.G);
+        const uint32_t idx = (w.G >> 8) + (pos ^ r.oct);
+        w.G &= w.G - 1u;
+        if (w.G & 0xFFu) {
+            if (KL > 0 && w.sp < KL) lds_stack[w.sp * 64 + lane] = w.G; else stack[w.sp - KL] = w.G;
+            ++w.sp;
+        }
+        pn = nodes + 5 * (size_t)idx;
+    }
+    const uint4 n0 = pn[0], n1 = pn[1], n2 = pn[2], n3 = pn[3], n4 = pn[4];
+    const uint4 u0 = pt[0], u1 = pt[1], u2 = pt[2];
+    asm volatile("" :: "v"(n0.x), "v"(n0.y), "v"(n0.z), "v"(n0.w), "v"(n1.x), "v"(n1.y), "v"(n1.z), "v"(n1.w), "v"(n2.x), "v"(n2.y), "v"(n2.z), "v"(n2.w) : "memory");
+    asm volatile("" :: "v"(n3.x), "v"(n3.y), "v"(n3.z), "v"(n3.w), "v"(n4.x), "v"(n4.y), "v"(n4.z), "v"(n4.w) : "memory");
+    asm volatile("" :: "v"(u0.x), "v"(u0.y), "v"(u0.z), "v"(u0.w), "v"(u1.x), "v"(u1.y), "v"(u1.z), "v"(u1.w), "v"(u2.x), "v"(u2.y), "v"(u2.z), "v"(u2.w) : "memory");
+    if (do_tri) {
+        float t_hi;
+        const int cls = tri_screen_f32(u0, u1, u2, r, dx, dy, dz, t_hi);
+        if (cls != 0) {
+            w.c3 = w.c2; w.c2 = w.c1; w.c1 = w.c0; w.c0 = ti; ++w.nc;
+            if (cls == 2) r.best = __builtin_fminf(r.best, t_hi);
+        }
+    }
+    if (do_node) {
+        uint32_t ih, lh;
+        bvh8_node(n0, n1, n2, n3, n4, r, ih, lh);
+        w.G = (n1.x << 8) | ih;
+        w.tw = n1.y | (lh << 24);
+        w.rank = n1.z;
+    }
+    return ((w.tw >> 24) != 0 || (w.G & 0xFFu) != 0 || w.sp > 0) ? kWalkOn : kWalkDone;
+}
+
 // `closest` / `prim` come in holding the best hit so far (spheres, LDS triangles) and go out updated; `slot` is the hit triangle's
 // position in the reordered array.
 template <class T, int KL = 0>
@@ -640,11 +838,12 @@ __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o,
     Bvh8Ray r; T t0;
     if (!bvh8_enter<T>(sc, o, d, closest, r, t0)) return;
     Bvh8Walk<T> w;
-    bvh8_begin<T>(w, r, t0);
+    bvh8_begin<T>(w, r, t0, t_min, sc.bvh_root[2].w);
     uint32_t stack[kBvhStackD - KL];
     const uint32_t lane = threadIdx.x & 63;
     const int base = (int)(sc.n_spheres + sc.n_triangles);
     while (bvh8_step<T, KL>(sc, w, r, o, d, t_min, base, closest, prim, slot, lds_stack, stack, lane)) {}
+    while (w.nc) bvh8_resolve_one<T>(sc, w, r, o, d, t_min, base, closest, prim, slot);      // (Float64: the candidates of the screened walk; Float32: never any)
 }
 
 // Linear scan with a shrinking t_max, examples/julia-raytracer.jl:242-258; spheres :113-142, triangles
@@ -1601,11 +1800,145 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
             uint32_t stack[kBvhStackD - kLdsStack];
             uint32_t next = 0;                                         // next unread entry (wave-uniform)
             MESH_STAT(const unsigned long long dbg_s0 = __builtin_readcyclecounter(); ++dbg_ns; dbg_rays += mfill;)
+#ifdef SPIRA_BVH_SCREEN
+            constexpr bool kScreened = sizeof(T) == 8;
+#else
+            constexpr bool kScreened = false;
+#endif
+            if constexpr (kScreened) {
+            // ---- Float64: the walk runs on Float32 screens (bvh8_step_screened) and a walking lane holds nothing of its ray in Float64: the parked entry is read
+            // again when the lane has finished, its candidates go through the scan's own Float64 test there (all finished lanes together: one round trip per
+            // candidate of the lane that holds the most), and the result is emitted as in the Float32 session below.
+            bool walking = false, finished = false, full = false;      // finished: a result waits to be emitted; full: the candidate list has to be emptied
+            uint32_t ent_i = 0;                                        // the lane's parked entry (index into a.mesh_list)
+            float dxf = 0, dyf = 0, dzf = 1;
+            Bvh8Ray ry; ry.ox = ry.oy = ry.oz = 0; ry.ix = ry.iy = ry.iz = 1; ry.oct = 0; ry.best = 0; ry.tmin = 0; ry.amin = 0;
+            Bvh8Walk<T> wk; wk.G = 0; wk.tw = 0; wk.rank = 0; wk.sp = 0; wk.t0 = 0; wk.c0 = wk.c1 = wk.c2 = wk.c3 = 0; wk.nc = 0;
+            auto decode = [&](const Pack4<T> A, const Pack4<T> B, const Pack4<T> C, Vec<T> &o_, Vec<T> &d_, Vec<T> &beta_, T &closest, uint32_t &q_, int &prim, uint32_t &slot, uint32_t &stage_hit) {
+                o_ = mk<T>(A.x, A.y, A.z); d_ = mk<T>(A.w, B.x, B.y); beta_ = mk<T>(B.z, B.w, C.x);
+                closest = C.y;
+                q_ = Bits<T>::to_u32(C.z);
+                const uint32_t pw = Bits<T>::to_u32(C.w);
+                prim = (int)(pw & kRefMask) - 1;                       // the closest object so far: a sphere / LDS triangle, or (an entry written back below) a mesh triangle
+                stage_hit = pw >> kStageShift;
+                slot = 0;
+                if (prim >= (int)ref_base) { slot = (uint32_t)prim - ref_base; prim = (int)ref_base; }
+            };
+            while (true) {
+                // ---- lanes whose candidate list is full: their candidates go through the exact test now, the result so far is written back into the entry (rare)
+                if (__any(full)) {
+                    if (full) {
+                        Pack4<T> *ent = a.mesh_list + 3 * (size_t)ent_i;
+                        const Pack4<T> A = ent[0], B = ent[1];
+                        Pack4<T> C = ent[2];
+                        Vec<T> o_, d_, beta_; T closest; uint32_t q_, slot, stage_hit; int prim;
+                        decode(A, B, C, o_, d_, beta_, closest, q_, prim, slot, stage_hit);
+                        while (wk.nc) bvh8_resolve_one<T>(sc, wk, ry, o_, d_, (T)0.001, (int)ref_base, closest, prim, slot);
+                        C.y = closest;
+                        C.w = Bits<T>::from_u32((uint32_t)((prim >= (int)ref_base ? (int)(ref_base + slot) : prim) + 1) | (stage_hit << kStageShift));
+                        ent[2] = C;
+                        full = false;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                // ---- emit what is finished (wave-uniform block)
+                {
+                    Vec<T> o_ = mk<T>(0, 0, 0), d_ = mk<T>(0, 0, 1), beta_ = mk<T>(0, 0, 0);
+                    T closest = 0; uint32_t q_ = 0, stage_hit = 0, slot = 0; int prim = -1;
+                    if (finished) {
+                        // the entry and the newest candidate's Float64 record in ONE round trip (most rays hold at most one candidate)
+                        const Pack4<T> *ent = a.mesh_list + 3 * (size_t)ent_i;
+                        const bool has = wk.nc != 0;
+                        const uint32_t ti = has ? wk.c0 : 0u;
+                        const Pack4<T> *rec = sc.bvh_tris + 3 * (size_t)ti;
+                        const Pack4<T> A = ent[0], B = ent[1], C = ent[2];
+                        const Pack4<T> v0 = rec[0], e1 = rec[1], e2 = rec[2];
+                        decode(A, B, C, o_, d_, beta_, closest, q_, prim, slot, stage_hit);
+                        if (has) {
+                            wk.c0 = wk.c1; wk.c1 = wk.c2; wk.c2 = wk.c3; --wk.nc;
+                            T t;
+                            if (triangle_test<T>(v0, e1, e2, o_, d_, (T)0.001, closest, t)) {
+                                const int p = (int)ref_base + (int)Bits<T>::to_u32(v0.w);
+                                if (t < closest || p > prim) { closest = t; prim = p; slot = ti; }      // t == closest: the later object wins
+                            }
+                        }
+                    }
+                    while (__any(finished && wk.nc != 0)) {
+                        if (finished && wk.nc != 0) bvh8_resolve_one<T>(sc, wk, ry, o_, d_, (T)0.001, (int)ref_base, closest, prim, slot);
+                    }
+                    const unsigned long long mh = __ballot(finished && prim >= 0);
+                    if (finished) {
+                        if (prim < 0) {                                   // the ray leaves the scene after all: sky, :365-366
+                            const uint32_t qi = q_ & 0x7FFFFFFFu;
+                            ExtState<T> ex1; ex1.flags = rc.flags; ex1.bR = 0; ex1.bG = 0; ex1.bB = 0;
+                            if (EXT && (rc.flags & kExtSpectral)) {
+                                uint32_t pi, pj, pixel, sample;
+                                path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
+                                (void)ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex1);
+                            }
+                            const Vec<T> c = sky_term_x<T, EXT>(d_, beta_, &ex1);
+                            Pack3<T> l; l.x = c.x; l.y = c.y; l.z = c.z;
+                            if (q_ >> 31) { const Pack3<T> l0 = a.L[qi]; l.x = l0.x + c.x; l.y = l0.y + c.y; l.z = l0.z + c.z; ++n_rmw; }
+                            else ++n_store;
+                            a.L[qi] = l;
+                        } else {
+                            const Vec<T> hp = o_ + d_ * closest;          // point_at, :138 / :183
+                            const uint32_t w_ = ((prim >= (int)ref_base) ? ref_base + slot : (uint32_t)prim) | (stage_hit << kStageShift);
+                            const uint32_t dst = region + fill + __popcll(mh & lt_mask);
+                            Pack4<T> A, B; Pack2<T> C;
+                            A.x = hp.x; A.y = hp.y; A.z = hp.z; A.w = d_.x;
+                            B.x = d_.y; B.y = d_.z; B.z = beta_.x; B.w = beta_.y;
+                            C.x = beta_.z; C.y = pack_qref(q_, w_, (T)0);
+                            qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
+                            if constexpr (kRefArray) rout[dst] = w_;
+                        }
+                    }
+                    fill += (uint32_t)__popcll(mh);
+                    finished = false;
+                }
+                // ---- refill the free lanes
+                const unsigned long long mf = __ballot(!walking);
+                const uint32_t take = min((uint32_t)__popcll(mf), mfill - next);
+                if (!walking && (uint32_t)__popcll(mf & lt_mask) < take) {
+                    const uint32_t e = next + (uint32_t)__popcll(mf & lt_mask);
+                    ent_i = region + e;
+                    if (segmented) {                               // entry e of the k lists taken over: which list, which entry of it
+                        uint32_t seg = 0, off = e;
+#pragma unroll
+                        for (int j = 1; j < kMaxSeg; ++j) if (e >= pfx[j]) { seg = (uint32_t)j; off = e - pfx[j]; }
+                        ent_i = (wid * kseg + seg) * a.cap + off;
+                    }
+                    const Pack4<T> *ent = a.mesh_list + 3 * (size_t)ent_i;
+                    const Pack4<T> A = ent[0], B = ent[1], C = ent[2];
+                    const Vec<T> o_ = mk<T>(A.x, A.y, A.z), d_ = mk<T>(A.w, B.x, B.y);
+                    T t0;
+                    if (bvh8_enter<T>(sc, o_, d_, C.y, ry, t0)) { bvh8_begin<T>(wk, ry, t0, (T)0.001, sc.bvh_root[2].w); dxf = (float)d_.x; dyf = (float)d_.y; dzf = (float)d_.z; walking = true; }
+                    else { wk.nc = 0; finished = true; }
+                }
+                next += take;
+                if (!__any(walking)) { if (__any(finished)) continue; break; }
+                // ---- walk; leave the loop when enough lanes are free for a refill to pay (or, with the list exhausted, when all are done), or a list is full
+                const bool more = next < mfill;
+                uint32_t n_now = (uint32_t)__popcll(__ballot(walking));
+                while (true) {
+                    ++n_wtrips; n_ltrips += n_now;
+                    if (walking) {
+                        const int st_ = bvh8_step_screened<kLdsStack>(sc.bvh_nodes, sc.bvh_tris32, wk, ry, dxf, dyf, dzf, lstack, stack, lane);
+                        if (st_ == kWalkDone) { walking = false; finished = true; }
+                        else if (st_ == kWalkFull) full = true;
+                    }
+                    const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+                    n_now = n_walk;
+                    if (n_walk == 0 || (more && 64u - n_walk >= a.refill_free) || __any(full)) break;
+                }
+            }
+            } else {
             bool walking = false, finished = false;                    // finished: a result waits to be emitted
             Vec<T> o_ = mk<T>(0, 0, 0), d_ = mk<T>(0, 0, 1), beta_ = mk<T>(0, 0, 0);
             T closest = 0; uint32_t q_ = 0, stage_hit = 0, slot = 0; int prim = -1;
-            Bvh8Ray ry; ry.ox = ry.oy = ry.oz = 0; ry.ix = ry.iy = ry.iz = 1; ry.oct = 0; ry.best = 0;
-            Bvh8Walk<T> wk; wk.G = 0; wk.tw = 0; wk.rank = 0; wk.sp = 0; wk.t0 = 0;
+            Bvh8Ray ry; ry.ox = ry.oy = ry.oz = 0; ry.ix = ry.iy = ry.iz = 1; ry.oct = 0; ry.best = 0; ry.tmin = 0; ry.amin = 0;
+            Bvh8Walk<T> wk; wk.G = 0; wk.tw = 0; wk.rank = 0; wk.sp = 0; wk.t0 = 0; wk.c0 = wk.c1 = wk.c2 = wk.c3 = 0; wk.nc = 0;
             while (true) {
                 // ---- emit what is finished, refill the free lanes (wave-uniform block)
                 const unsigned long long mh = __ballot(finished && prim >= 0);
@@ -1657,7 +1990,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                     stage_hit = pw >> kStageShift;
                     slot = 0;
                     T t0;
-                    if (bvh8_enter<T>(sc, o_, d_, closest, ry, t0)) { bvh8_begin<T>(wk, ry, t0); walking = true; }
+                    if (bvh8_enter<T>(sc, o_, d_, closest, ry, t0)) { bvh8_begin<T>(wk, ry, t0, (T)0.001, sc.bvh_root[2].w); walking = true; }
                     else finished = true;
                 }
                 next += take;
@@ -1674,7 +2007,9 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                     n_now = n_walk;
                     if (n_walk == 0 || (more && 64u - n_walk >= a.refill_free)) break;
                 }
+
                 MESH_STAT(dbg_walk += __builtin_readcyclecounter() - dbg_w0;)
+            }
             }
             mfill = 0;
             segmented = false;                                         // from here on the list is the wave's own (the lists taken over are spent)

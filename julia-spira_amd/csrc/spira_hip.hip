@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -88,11 +89,11 @@ struct DevBuf {
 // The context owns one (re-uploaded per call, the BVH cached by a hash of the triangle bytes); every
 // spira_scene handle owns one (validated, built and uploaded once by spira_scene_create_*).
 struct SceneStore {
-    DevBuf arrays, bvh_nodes, bvh_tris;
+    DevBuf arrays, bvh_nodes, bvh_tris, bvh_tris32;      // (bvh_tris32: Float64 scenes only — the Float32 screening records of the walk)
     uint32_t ns = 0, nm = 0, nt = 0;
     uint64_t bvh_hash = 0; uint32_t bvh_n = 0, bvh_slots = 0; int bvh_prec = 0, bvh_depth = 0;
     bool moderate = false;                    // every coordinate / radius of ordinary magnitude (spira::scene_scale_moderate): speculative division pays
-    void release() { arrays.release(); bvh_nodes.release(); bvh_tris.release(); bvh_hash = 0; bvh_n = 0; }
+    void release() { arrays.release(); bvh_nodes.release(); bvh_tris.release(); bvh_tris32.release(); bvh_hash = 0; bvh_n = 0; }
 };
 
 struct Ctx {
@@ -284,6 +285,7 @@ void scene_pointers(const SceneStore &s, spira::SceneGlobal<T> &g) {
     g.bvh_nodes = use_bvh ? (const uint4 *)s.bvh_nodes.p : nullptr;
     g.bvh_frame = use_bvh ? (const spira::Pack4<T> *)s.bvh_tris.p : nullptr;          // 3 packets ahead of the triangles
     g.bvh_tris = use_bvh ? (const spira::Pack4<T> *)s.bvh_tris.p + 3 : nullptr;
+    g.bvh_tris32 = (use_bvh && sizeof(T) == 8) ? (const uint4 *)s.bvh_tris32.p : nullptr;
     g.n_bvh_tris = use_bvh ? s.nt : 0;
     g.bvh_slots = use_bvh ? s.bvh_slots : 0;
 }
@@ -292,13 +294,19 @@ void scene_pointers(const SceneStore &s, spira::SceneGlobal<T> &g) {
 template <class T> struct HostBvh {
     spira::RawVec<uint32_t> nodes;
     spira::RawVec<spira::HostPack4<T>> tris;
+    spira::RawVec<spira::HostPack4<float>> tris32;          // Float64 only
     spira::HostPack4<T> frame[3];
     uint32_t slots = 0; int depth = 0; bool built = false;
 };
 template <class T>
 int host_bvh_build(const T *triangles10, uint32_t nt, HostBvh<T> &hb) {
     spira::BvhFrame<T> fr{};
-    if (!spira::bvh_build<T>(triangles10, nt, hb.nodes, hb.tris, fr))
+#ifdef SPIRA_BVH_SCREEN
+    constexpr bool kScreenRecords = sizeof(T) == 8;      // experiment build: Float64 walks screen their triangles in Float32 (spira_device.h, tri_screen_f32)
+#else
+    constexpr bool kScreenRecords = false;
+#endif
+    if (!spira::bvh_build<T>(triangles10, nt, hb.nodes, hb.tris, fr, 0, kScreenRecords ? &hb.tris32 : nullptr))
         return fail(SPIRA_E_LIMIT, "BVH build failed (tree too deep / too many triangles)");
     hb.frame[0] = {fr.root_mn[0], fr.root_mn[1], fr.root_mn[2], (T)0}; hb.frame[1] = {fr.root_mx[0], fr.root_mx[1], fr.root_mx[2], (T)0};
     hb.frame[2] = {fr.centre[0], fr.centre[1], fr.centre[2], fr.scale};
@@ -327,9 +335,10 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
     HIP_TRY(hipMemcpyAsync((void *)g.materials8, materials8, nm_b, hipMemcpyHostToDevice, st));
     if (nt_b) HIP_TRY(hipMemcpyAsync((void *)g.triangles10, triangles10, nt_b, hipMemcpyHostToDevice, st));
     if (use_bvh) {
-        const uint64_t h = spira::bytes_hash64(triangles10, (size_t)nt * 10 * sizeof(T));
+        // the context's store keeps the tree of the last mesh it saw, found again by a hash of the triangle bytes; a handle's store is filled once (no hash)
+        const uint64_t h = shared ? 0 : spira::bytes_hash64(triangles10, (size_t)nt * 10 * sizeof(T));
         lap("hash");
-        if (s.bvh_hash != h || s.bvh_n != nt || s.bvh_prec != (int)sizeof(T)) {
+        if (shared || s.bvh_hash != h || s.bvh_n != nt || s.bvh_prec != (int)sizeof(T)) {
             HostBvh<T> local;
             HostBvh<T> &hb = shared ? *shared : local;
             if (!hb.built) { if (int rc = host_bvh_build<T>(triangles10, nt, hb)) return rc; }
@@ -338,6 +347,8 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
             // (+ one record of padding each: a walk's trip loads 5 / 6 x 16 bytes from a node or a triangle alike, spira_device.h bvh8_step)
             if (int rc = s.bvh_nodes.ensure(hb.nodes.size() * sizeof(hb.nodes[0]) + 128)) return rc;
             if (int rc = s.bvh_tris.ensure(sizeof hb.frame + hb.tris.size() * sizeof(hb.tris[0]) + 128)) return rc;
+            const size_t tris32_b = hb.tris32.size() * sizeof(spira::HostPack4<float>);
+            if (tris32_b) { if (int rc = s.bvh_tris32.ensure(tris32_b + 128)) return rc; }
             lap("hipMalloc");
             // The three arrays go up as asynchronous copies out of the vectors pinned in place (hipHostRegister: ~11 MB for 82 k triangles in Float64;
             // a hipMemcpy from pageable memory is staged by the runtime chunk by chunk on this thread), one wait at the end: the host vectors may die
@@ -345,14 +356,17 @@ int scene_upload(SceneStore &s, hipStream_t st, hipEvent_t prev_done, const T *s
             const size_t nodes_b = hb.nodes.size() * sizeof(hb.nodes[0]), tris_b = hb.tris.size() * sizeof(hb.tris[0]);
             const bool pin_n = hipHostRegister(hb.nodes.data(), nodes_b, hipHostRegisterDefault) == hipSuccess;
             const bool pin_t = hipHostRegister(hb.tris.data(), tris_b, hipHostRegisterDefault) == hipSuccess;
-            if (!pin_n || !pin_t) (void)hipGetLastError();
+            const bool pin_s = tris32_b && hipHostRegister(hb.tris32.data(), tris32_b, hipHostRegisterDefault) == hipSuccess;
+            if (!pin_n || !pin_t || (tris32_b && !pin_s)) (void)hipGetLastError();
             hipError_t e1 = hipMemcpyAsync(s.bvh_nodes.p, hb.nodes.data(), nodes_b, hipMemcpyHostToDevice, st);
             hipError_t e2 = hipMemcpyAsync(s.bvh_tris.p, hb.frame, sizeof hb.frame, hipMemcpyHostToDevice, st);
             hipError_t e3 = hipMemcpyAsync((char *)s.bvh_tris.p + sizeof hb.frame, hb.tris.data(), tris_b, hipMemcpyHostToDevice, st);
+            hipError_t e5 = tris32_b ? hipMemcpyAsync(s.bvh_tris32.p, hb.tris32.data(), tris32_b, hipMemcpyHostToDevice, st) : hipSuccess;
             hipError_t e4 = hipStreamSynchronize(st);
             if (pin_n) (void)hipHostUnregister(hb.nodes.data());
             if (pin_t) (void)hipHostUnregister(hb.tris.data());
-            HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
+            if (pin_s) (void)hipHostUnregister(hb.tris32.data());
+            HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e5); HIP_TRY(e4);
             lap("pin+copy");
             const int depth = hb.depth;
             s.bvh_slots = hb.slots;
@@ -577,6 +591,63 @@ int check_handle(const spira_scene *h) {
     return 0;
 }
 
+// ---- workspaces of the persistent organisation, sized and checked in ONE place.
+// PathPlan says what the passes of a call may touch (derived from the launch geometry); ensure_path_plan() sizes every buffer a launch can be handed;
+// verify_path_args() — called right before every k_path launch — checks each pointer of PathArgs against the capacity of the buffer it points into for
+// the grid about to be launched, and refuses the launch (SPIRA_E_LIMIT) instead of letting a kernel write past a buffer nobody sized.  (Round 3's
+// fuzz found exactly that: a depth-1 mesh render writing parked rays' hits into queues only `max_depth > 1` used to size.)
+struct PathPlan {
+    uint64_t waves = 0;        // NW of the largest pass (G_max * waves per workgroup)
+    uint64_t packets = 0;      // NW * cap of the largest pass: entries of every per-packet array (worst case: every path queued / parked once)
+    uint64_t batch = 0;        // paths of the largest pass (entries of L)
+    bool queues = false;       // hit queues: max_depth > 1, or a mesh scene (a parked camera ray's hit comes back from its session as a packet)
+    bool mesh = false;         // mesh lists (deferred traversal)
+    bool two_pass = false;     // per-wave parked counts handed from the parking launch to the fat-wave launch
+    bool spec = false;         // per-wave redo flags of the speculative-division launch
+};
+template <class T>
+int ensure_path_plan(Ctx &c, const PathPlan &pl) {
+    using P4 = spira::Pack4<T>;
+    using P2 = spira::Pack2<T>;
+    if (pl.queues)
+        for (int i = 0; i < 2; ++i) {
+            if (int rc = c.qA[i].ensure(pl.packets * sizeof(P4))) return rc;
+            if (int rc = c.qB[i].ensure(pl.packets * sizeof(P4))) return rc;
+            if (int rc = c.qC[i].ensure(pl.packets * sizeof(P2))) return rc;
+            if (sizeof(T) == 4) { if (int rc = c.qR[i].ensure(pl.packets * sizeof(uint32_t))) return rc; }
+        }
+    if (pl.mesh) { if (int rc = c.mesh_list.ensure(3 * pl.packets * sizeof(P4))) return rc; }
+    if (pl.two_pass) { if (int rc = c.mesh_count.ensure(pl.waves * sizeof(uint32_t))) return rc; }
+    if (pl.spec) { if (int rc = c.redo.ensure(pl.waves * sizeof(uint32_t))) return rc; }
+    if (int rc = c.blkstats.ensure(pl.waves * 4 * sizeof(uint32_t))) return rc;
+    if (int rc = c.L.ensure(pl.batch * sizeof(spira::Pack3<T>))) return rc;
+    return c.stats.ensure(sizeof(spira::Stats));
+}
+template <class T>
+int verify_path_args(const Ctx &c, const spira::PathArgs<T> &a, uint32_t first_launch_blocks) {
+    using P4 = spira::Pack4<T>;
+    using P2 = spira::Pack2<T>;
+    const uint64_t nw = (uint64_t)first_launch_blocks * (spira::kBlock / 64), n = nw * a.cap;      // (a fat wave of the second launch owns the regions of the waves it takes over: the same n)
+    auto covers = [](const DevBuf &b, const void *ptr, uint64_t bytes) { return ptr == b.p && b.p != nullptr && b.cap >= bytes; };
+    const char *bad = nullptr;
+    const bool mesh = a.scene.n_bvh_tris != 0;
+    if ((uint64_t)a.n_first > n) bad = "the pass does not fit its queue regions";
+    if (a.rc.max_depth > 1 || mesh)
+        for (int i = 0; i < 2 && !bad; ++i) {
+            if (!covers(c.qA[i], a.q[i].A, n * sizeof(P4)) || !covers(c.qB[i], a.q[i].B, n * sizeof(P4)) || !covers(c.qC[i], a.q[i].C, n * sizeof(P2))) bad = "hit queues";
+            else if (sizeof(T) == 4 && !covers(c.qR[i], a.qref[i], n * sizeof(uint32_t))) bad = "hit reference arrays";
+        }
+    if (!bad && a.mesh_list && !covers(c.mesh_list, a.mesh_list, 3 * n * sizeof(P4))) bad = "mesh lists";
+    if (!bad && a.mesh_mode != 0 && (!a.mesh_list || !covers(c.mesh_count, a.mesh_count, nw * sizeof(uint32_t)) || a.resume_k == 0 || a.resume_k > 16 || nw % a.resume_k != 0 || a.resume_nw != nw))
+        bad = "parked-ray counts of a two-launch mesh pass";
+    if (!bad && a.redo && !covers(c.redo, a.redo, nw * sizeof(uint32_t))) bad = "redo flags";
+    if (!bad && !covers(c.blkstats, a.blk_stats, nw * 4 * sizeof(uint32_t))) bad = "per-wave statistics";
+    if (!bad && !covers(c.L, a.L, (uint64_t)a.n_first * sizeof(spira::Pack3<T>))) bad = "per-path radiance";
+    if (!bad && !covers(c.stats, a.stats, sizeof(spira::Stats))) bad = "counters";
+    if (bad) return fail(SPIRA_E_LIMIT, std::string("internal: a workspace is smaller than the launch needs (") + bad + ")");
+    return 0;
+}
+
 template <class T>
 int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
                 T *out_hdr, T *out_img, bool out_on_device, void *user_stream,
@@ -584,6 +655,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     // progressive: out_hdr is the caller's running SUM (in/out), samples [sample0, sample0 + spp) are added to it
     uint32_t rows = 0;
     if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    tl_lds_optin = hipSuccess;           // (a flag an earlier call of this thread left behind by returning early must not fail this one)
     Lap lap("render");
     if (h) { if (int rc = check_handle<T>(h)) return rc; }
     else if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, triangles10 ? p->n_triangles : 0)) return rc;
@@ -651,22 +723,30 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     // ---- workspaces (cached per device, grown on demand; sized for 288 GB HBM: no chunking of a pass)
     using P4 = spira::Pack4<T>;
     using P2 = spira::Pack2<T>;
+    const bool mesh_scene = nt_scene > SPIRA_LDS_TRIANGLES;
+    const bool defer_mesh = persistent && mesh_scene && p->max_depth <= 128 && env_u32("SPIRA_DEFER_MESH", 1) != 0;
+    // speculative division (spira_device.h, SpecDiv): decided here once, because it needs a workspace (the per-wave redo flags) — see the launch below
+    PathPlan plan;
+    plan.waves = (uint64_t)G_max * wpb; plan.packets = q_rays; plan.batch = batch;
     // (max_depth == 1 needs no queue — except on a mesh scene of the persistent organisation: a parked camera ray's hit comes back from its
-    //  traversal session as a packet.  The condition used to be max_depth > 1 alone: a depth-1 mesh render wrote into whatever queues an earlier,
-    //  possibly smaller call had left — found by the fuzz campaign of seed 4041, case 17, as an abort of the process.)
-    if (!mega && (p->max_depth > 1 || (persistent && nt_scene > SPIRA_LDS_TRIANGLES)))
-        for (int i = 0; i < 2; ++i) {
-            if (int rc = c.qA[i].ensure(q_rays * sizeof(P4))) return rc;
-            if (int rc = c.qB[i].ensure(q_rays * sizeof(P4))) return rc;
-            if (int rc = c.qC[i].ensure(q_rays * sizeof(P2))) return rc;
-            if (persistent && sizeof(T) == 4) { if (int rc = c.qR[i].ensure(q_rays * sizeof(uint32_t))) return rc; }
-        }
-    if (int rc = c.L.ensure(batch * sizeof(spira::Pack3<T>))) return rc;
+    //  traversal session as a packet.)
+    plan.queues = !mega && (p->max_depth > 1 || (persistent && mesh_scene));
+    plan.mesh = defer_mesh; plan.two_pass = defer_mesh && mesh_two_pass; plan.spec = persistent && env_u32("SPIRA_SPEC_DIV", 1) != 0;
+    if (persistent) { if (int rc = ensure_path_plan<T>(c, plan)) return rc; }
+    else {
+        if (plan.queues)
+            for (int i = 0; i < 2; ++i) {
+                if (int rc = c.qA[i].ensure(q_rays * sizeof(P4))) return rc;
+                if (int rc = c.qB[i].ensure(q_rays * sizeof(P4))) return rc;
+                if (int rc = c.qC[i].ensure(q_rays * sizeof(P2))) return rc;
+            }
+        if (int rc = c.L.ensure(batch * sizeof(spira::Pack3<T>))) return rc;
+        // per-wave survivor counts exist in the per-bounce organisation only; statistics: one row per wave per launch
+        if (per_bounce) { if (int rc = c.counts.ensure((size_t)(p->max_depth + 2) * G_max * wpb * sizeof(uint32_t))) return rc; }
+        if (int rc = c.blkstats.ensure((size_t)(per_bounce ? p->max_depth + 1 : 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
+        if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
+    }
     if (int rc = c.accum.ensure(tile_pixels * sizeof(P4))) return rc;
-    // per-wave survivor counts exist in the per-bounce organisation only; statistics: one row per wave per launch
-    if (per_bounce) { if (int rc = c.counts.ensure((size_t)(p->max_depth + 2) * G_max * wpb * sizeof(uint32_t))) return rc; }
-    if (int rc = c.blkstats.ensure((size_t)(per_bounce ? p->max_depth + 1 : 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
-    if (int rc = c.stats.ensure(sizeof(spira::Stats))) return rc;
 
     lap("workspaces");
     spira::BounceArgs<T> a{};
@@ -765,6 +845,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
         }
         if (R == 2) launch_lds(spira::k_path_metal<T, 2, false>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
         else launch_lds(spira::k_path_metal<T, 1, false>, dim3(Gm), dim3(spira::kBlock), lds, st, ma);
+        if (int rc = lds_optin_failed()) return rc;
         HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
         hipLaunchKernelGGL(spira::k_fold_stats, dim3(1), dim3(64), 0, st, (const uint32_t *)c.blkstats.p, Gm * wpb, (spira::Stats *)c.stats.p);
         launches += 2;
@@ -826,11 +907,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 // pays to keep a little more in registers there.  On the closed box S3 any threshold > 0 gives the full +22 % (f64).
                 pa.dense_pct = std::min<uint32_t>(env_u32("SPIRA_DENSE_PCT", 80), 100);      // (Float32 re-measured on the no-SLP build, S1: 90: 37 900, 85: 38 500, 80: 38 500, 75: 38 500, 70: 37 500)
                 // BVH scenes: the wave-owned lists of rays waiting for their dense traversal batch (3 packets per entry, `cap` entries per wave)
-                pa.mesh_list = nullptr;
-                if (a.scene.n_bvh_tris && p->max_depth <= 128 && env_u32("SPIRA_DEFER_MESH", 1)) {
-                    if (int rc = c.mesh_list.ensure(3 * q_rays * sizeof(P4))) return rc;
-                    pa.mesh_list = (P4 *)c.mesh_list.p;
-                }
+                pa.mesh_list = plan.mesh ? (P4 *)c.mesh_list.p : nullptr;
                 geometry(n_first, G, pa.cap);
                 stat_rows = G * wpb;
                 for (int i = 0; i < 2; ++i) {
@@ -845,16 +922,12 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 int spec = (int)env_u32("SPIRA_SPEC_DIV", 1);
                 if (spec == 1 && !(scene_moderate && spira::camera_scale_moderate<T>(camera12))) spec = 0;
                 if (spec == 3) spec = 1;
-                if (spec) {
-                    if (int rc = c.redo.ensure((size_t)G_max * wpb * sizeof(uint32_t))) return rc;
-                    pa.redo = (uint32_t *)c.redo.p;
-                }
+                if (spec) pa.redo = (uint32_t *)c.redo.p;      // (sized by the plan whenever SPIRA_SPEC_DIV != 0)
                 pa.mesh_mode = 0; pa.mesh_count = nullptr; pa.resume_k = 1; pa.resume_nw = 0;
                 pa.mesh_min_batch = std::max<uint32_t>(1, env_u32("SPIRA_MESH_MIN_BATCH", 128));
                 pa.refill_free = std::min<uint32_t>(64, std::max<uint32_t>(1, env_u32("SPIRA_MESH_REFILL", 16)));
                 const size_t lds_a = lds + (size_t)wpb * sub * sizeof(P4) + 128;       // + one work list per wave + the camera
-                if (mesh_two_pass && pa.mesh_list) {
-                    if (int rc = c.mesh_count.ensure((size_t)G_max * wpb * sizeof(uint32_t))) return rc;
+                if (plan.two_pass) {
                     pa.mesh_mode = 1; pa.mesh_count = (uint32_t *)c.mesh_count.p;
                     // the fat waves of the second launch: about 16 per CU (4 per SIMD), each taking over k <= 16 first-launch waves; k divides their number
                     const uint32_t nw = G * wpb, fat = std::max<uint32_t>(1, (uint32_t)c.num_cus * env_u32("SPIRA_MESH_FAT_WAVES_PER_CU", 16));
@@ -862,8 +935,10 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                     while (k > 1 && (nw % k != 0 || nw / k < fat)) k >>= 1;
                     pa.resume_k = k; pa.resume_nw = nw;
                 }
+                if (int rc = verify_path_args<T>(c, pa, G)) return rc;      // every pointer against the capacity of its buffer, for THIS grid
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                 if (int rc = launch_path<T>(R, dim3(G), lds_a, st, pa, spec)) return rc;
+                if (int rc = lds_optin_failed()) return rc;      // (a kernel that was refused its LDS did not run: nothing that consumes its output is enqueued)
                 launches += (spec && R == 2) ? 2 : 1;      // the speculative launch and its exact follow-up
                 if (pa.mesh_mode == 1) {           // second launch: nw / k fat waves
                     if (c.ev_mid.size() <= c.ev_mid_used) {
@@ -877,6 +952,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                     pb.mesh_mode = 2; pb.n_first = 0;
                     const uint32_t nwb = pa.resume_nw / pa.resume_k;
                     launch_path_resume_entry<T>(R, dim3((nwb + wpb - 1) / wpb), lds_a, st, pb);
+                    if (int rc = lds_optin_failed()) return rc;
                     ++launches;
                 }
                 HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
@@ -896,6 +972,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                     const size_t lds_b = lds + (size_t)wpb * sub * sizeof(P4);   // + one work list per wave (one slot per ray of a sub-chunk)
                     if (b == 0) launch_bounce<T, true>(R, dim3(G), lds_b, st, a);
                     else launch_bounce<T, false>(R, dim3(G), lds_b, st, a);
+                    if (int rc = lds_optin_failed()) return rc;
                     if (profile) HIP_TRY(hipEventRecord(c.ev_pool[c.ev_used++], st));
                     ++launches;
                 }
@@ -962,6 +1039,7 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
                uint32_t n_paths, const uint32_t *ijs, int *prims, T *ts, T *dirs, T *radiance) {
     uint32_t rows = 0;
     if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
+    tl_lds_optin = hipSuccess;
     if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, triangles10 ? p->n_triangles : 0)) return rc;
     if (int rc = validate_params(camera12, p, triangles10 ? p->n_triangles : 0, &rows)) return rc;
     if (!n_paths || !ijs || !prims || !ts || !dirs || !radiance) return fail(SPIRA_E_INVALID, "NULL argument");
@@ -1214,7 +1292,7 @@ int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materia
 
     std::vector<int> rcs(n, 0);
     std::vector<std::string> errs(n);
-    bool exchange_failed = false;
+    std::atomic<bool> exchange_failed{false};      // (set by any worker thread whose gate reports a failed exchange)
     const int caller_device = tl_device;
     // Every device finishes (or fails) its allocation + render-enqueue phase before any of them enters the exchange: a device that
     // failed early must not leave device 0 waiting on the stream for a tile that will never be sent.

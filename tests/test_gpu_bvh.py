@@ -249,3 +249,34 @@ def test_depth_one_mesh_render_allocates_its_own_queues(gpu, oracle, prec):
     hdr, _ = gpu.render(*_args(s), gpu.make_params(62, 52, 7, 1, ns, nm, nt, flags=gpu.POST_NONE, seed=766849796527), prec)
     ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(62, 52, 7, 1, ns, nm, nt, flags=gpu.POST_NONE, seed=766849796527), prec)
     assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg
+
+
+def test_float32_triangle_screen_contract(tmp_path):
+    """The Float32 screen of a Float64 walk (spira_device.h, tri_screen_f32; an experiment build, measured slower and not the default) must never
+    reject a triangle the scan's own Float64 test accepts, and what it calls a certain hit must be one, within its distance bound:
+    tests/native/tri_screen.hip over 2^28 adversarial ray / triangle pairs (edges, vertices, grazing rays, slivers, meshes far from the origin)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tri_screen")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"),
+                    "-o", exe, os.path.join(root, "tests", "native", "tri_screen.hip")], check=True, timeout=600)
+    out = subprocess.run([exe, "1024", "1024", "20261005"], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0 and "screened out 0;" in out.stdout and "of those wrong 0" in out.stdout, out.stdout + out.stderr
+
+
+def test_screened_float64_walk_experiment_build():
+    """`make screen` (csrc/Makefile): the library with the Float64 walk run on Float32 screens + batched exact tests.  Not the default (2 .. 6 % slower,
+    DESIGN.md / docs/experiments.md) — but it must return exactly the linear scan's result like the default walk: the bit-exact mesh tests of this file
+    (Float64) run on it in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "julia-spira_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "screen"], check=True, timeout=900)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "(bit_exact or image_matches or organisations_and_session_knobs or normalised_frame or far_camera or depth_one or deferred) and not experiment"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SPIRA_HIP_LIB=os.path.join(csrc, "libspira_hip_screen.so")), cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -218,3 +218,19 @@ def test_concurrent_host_threads_share_one_device_context(gpu):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_plain_flags_library():
+    """The Makefile drops its LLVM-internal flag when hipcc rejects it (csrc/Makefile, MAIN_LLVM_OK); `make plain` builds that fallback library on
+    purpose — the three translation units with plain flags only.  It must load, carry the same ABI and pass the smoke checks (HIP path == oracle,
+    spheres and the mesh path, both precisions, the three organisations): speed is what the special flags buy, never results."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "julia-spira_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "plain"], check=True)          # (built by __graft_entry__.build(); a no-op when it travelled with the snapshot)
+    lib = os.path.join(csrc, "libspira_hip_plain.so")
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; from spira_hip import _binding as B; "
+            "assert B.LIB_PATH.endswith('libspira_hip_plain.so') and B.build_id() == 'plain-flags', (B.LIB_PATH, B.build_id()); g.smoke()" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SPIRA_HIP_LIB=lib), timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
