@@ -34,7 +34,8 @@ sys.path[:0] = [os.path.join(ROOT, "julia-spira_amd"), os.path.join(ROOT, "oracl
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 SCENE_DESC = {"s1": "create_scene() of src/spira-metal-optimized.jl", "s2": "create_scene() of examples/julia-raytracer.jl",
               "s3": "S1 inside a closed box", "s4": "create_scene_with_obj() of examples/julia-raytracer.jl with an 81 920-triangle procedural mesh (BVH)",
-              "s5": "S4's objects seen from 16 cm in front of the mesh: it fills 70 % of the frame (mesh-path stress scene)"}
+              "s5": "S4's objects seen from 16 cm in front of the mesh: it fills 70 % of the frame (mesh-path stress scene)",
+              "s2g": "create_scene() of examples/julia-raytracer.jl with two glass spheres and a glass triangle (extension scene, parity unpinned)"}
 CONFIGS = {   # BASELINE.json configs[2..4]: scene, spp, depth, spp is per GPU (weak) or in total (strong)
     "c3": dict(scene="s1", spp=64, depth=8, scaling="weak", name="BASELINE configs[2]"),
     "c4": dict(scene="s3", spp=256, depth=8, scaling="strong", name="BASELINE configs[3]"),      # BASELINE.md §3 / SURVEY §8d: c4 runs on S3
@@ -98,7 +99,7 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape, source_hash=None)
            "parked_per_sample": round(c.get("rays_parked", 0) / c["samples"], 4),
            "kernel_share_of_step": round(kms / max(c["kernel_ms"], 1e-9), 4),
            # k_path: the speculative-division launch + the exact follow-up over the waves it reported; both inside avg_launch_ms
-           "waves_rendered_again": int(c.get("redone_waves", 0)), "valu": None}
+           "waves_rendered_again": int(c.get("redone_waves", 0)), "valu": None, "compute": None}
     if c.get("rays_parked", 0) and c.get("mesh_wave_trips", 0):
         # the traversal side of a mesh scene: rays that reach the mesh's box wait on a list and are walked through the 8-wide tree in sessions
         # (second, fat-wave launch of the pass); a trip = one memory round trip of a lane (a node visit, a triangle test, or both in Float32)
@@ -135,6 +136,13 @@ def roofline_record(c, prec, kernel, scene, is_headline_shape, source_hash=None)
                                "source": rec["traffic_source"]}
                 if v["issue_slots"] > rec["frac"]:
                     rec["bound"] = "valu"
+            # the compute side as a fraction in (0, 1]: the kernel's dynamic instruction mix at data-sheet issue costs over the measured SIMD cycles per instruction
+            # (profiles/summarize.py); the bound is whichever side of the roofline is closer to its ceiling
+            cp = tj.get("compute")
+            if cp and cp.get("issue_util"):
+                rec["compute"] = {k: cp.get(k) for k in ("issue_util", "issue_util_priced", "min_cycles_per_inst_spec", "min_cycles_per_inst_priced", "flops_frac", "tflops",
+                                                         "non_arithmetic_share", "what")}
+                rec["bound"] = "valu" if cp["issue_util"] > rec["frac"] else "hbm"
     return rec
 
 
@@ -228,7 +236,7 @@ def main():
     depth = args.depth if args.depth is not None else cfg["depth"]
     spp_cfg = args.spp if args.spp is not None else cfg["spp"]
     spp_total = spp_cfg * world if cfg["scaling"] == "weak" else spp_cfg
-    builders = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3, "s4": scenes.scene_s4, "s5": scenes.scene_s5}
+    builders = {"s1": scenes.scene_s1, "s2": scenes.scene_s2, "s3": scenes.scene_s3, "s4": scenes.scene_s4, "s5": scenes.scene_s5, "s2g": scenes.scene_s2_glass}
     kflags = {"wavefront": B.KERNEL_WAVEFRONT, "bounce": B.KERNEL_BOUNCE, "mega": B.KERNEL_MEGA}
     seed = scenes.seed_for({"c3": 3, "c4": 4, "c5": 5}[args.config])
     tile = D.tile_params(H, world, rank)
@@ -311,10 +319,10 @@ def main():
     samples_per_step = W * H * spp_total
     value = samples_per_step * args.steps / dt / 1e6
 
-    def side_run(scene, kernel, prec, reps=5, sem=0, spp=None, dep=None, seed_=None):
-        """An extra, untimed-region measurement on rank 0: (Msamples/s, ms per step, roofline record)."""
+    def side_run(scene, kernel, prec, reps=5, sem=0, spp=None, dep=None, seed_=None, ext=0):
+        """An extra, untimed-region measurement on rank 0: (Msamples/s, ms per step, roofline record).  ext: SPIRA_EXT_* flags."""
         sc2, counts2 = workload(scene)
-        fl = kflags[kernel] | B.POST_NONE | sem
+        fl = kflags[kernel] | B.POST_NONE | sem | ext
         spp_ = spp_total if spp is None else spp
         dep_ = depth if dep is None else dep
         pp = B.make_params(W, H, spp_, dep_, *counts2, flags=fl, seed=seed if seed_ is None else seed_, **tile)
@@ -343,7 +351,7 @@ def main():
         elif sem:
             roof = {"segments_per_sample": round(c["segments"] / c["samples"], 4)}
         elif kernel == "wavefront":
-            roof = roofline_record(c, prec, kernel, scene, (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12, "s5": 12}.get(scene, 8), src_hash)
+            roof = roofline_record(c, prec, kernel, scene + ("_ext" if ext else ""), (W, H, world) == (1920, 1080, 1) and spp_ % 64 == 0 and dep_ == {"s4": 12, "s5": 12}.get(scene, 8), src_hash)
         elif kernel == "bounce":     # per-bounce launches are only bracketed on request (it slows the render): one extra, profiled render
             B.render_device(*sc2, B.make_params(W, H, spp_, dep_, *counts2, flags=fl | B.FLAG_PROFILE, seed=seed, **tile),
                             o2.data_ptr(), 0, stream.cuda_stream, prec)
@@ -369,7 +377,7 @@ def main():
             v, ms, aroof = side_run(scene_name, args.kernel, ap_)
             alt = {"dtype": ap_, "value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": aroof}
         # ---- stress scene and the other kernel organisations (N=1 only; informational)
-        stress, stress_mesh, orgs, estimators = None, None, None, None
+        stress, stress_mesh, extensions, orgs, estimators = None, None, None, None, None
         if world == 1 and not args.no_extras:
             if scene_name != "s3" and args.config != "c5":
                 v, ms, sroof = side_run("s3", args.kernel, args.prec)
@@ -382,6 +390,20 @@ def main():
                 for pr in ("f64", "f32"):
                     v, ms, sroof = side_run("s5", "wavefront", pr, reps=3, spp=64, dep=12, seed_=scenes.seed_for(6))
                     stress_mesh[pr] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "roofline": sroof}
+            if (W, H) == (1920, 1080):
+                # the extensions north_star / configs[4] name ("spectral SPD", dielectric BSDF; README.md:10): no reference code exists for them (parity unpinned),
+                # their own EXT = true instantiations of k_path.  configs[4] with SPIRA_EXT_SPECTRAL, and the glass scene with both extensions at the headline shape.
+                extensions = {"what": "SPIRA_EXT_* extensions (include/spira_hip.h; the reference only names them: parity unpinned): c5_spectral = BASELINE configs[4] with hero-wavelength "
+                                      "spectral transport (SPD tables in LDS); s2_glass = examples/julia-raytracer.jl's scene with two glass spheres and a glass triangle, dielectric + spectral, "
+                                      "1080p spp 64 depth 8; vs_plain = frame time over the same frame without the extension flags"}
+                for key, scn, spp_e, dep_e, fl_e, seed_e in (("c5_spectral", "s4", 64, 12, B.EXT_SPECTRAL, scenes.seed_for(5)),
+                                                          ("s2_glass", "s2g", 64, 8, B.EXT_DIELECTRIC | B.EXT_SPECTRAL, scenes.seed_for(7))):
+                    entry = {"workload": "%dx%d spp=%d depth=%d, scene %s (%s), flags 0x%x" % (W, H, spp_e, dep_e, scn, SCENE_DESC[scn], fl_e), "metric": metric_string(W, H, spp_e, dep_e)}
+                    for pr in ("f64", "f32"):
+                        v, ms, eroof = side_run(scn, "wavefront", pr, reps=3, spp=spp_e, dep=dep_e, seed_=seed_e, ext=fl_e)
+                        v0, ms0, _ = side_run(scn, "wavefront", pr, reps=3, spp=spp_e, dep=dep_e, seed_=seed_e)
+                        entry[pr] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "plain_ms_per_step": round(ms0, 3), "vs_plain": round(ms / ms0, 4), "roofline": eroof}
+                    extensions[key] = entry
             orgs = {}
             for k in ("wavefront", "bounce", "mega"):
                 if k != args.kernel:
@@ -500,7 +522,7 @@ def main():
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": scene_name, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
-            "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "scene_build": scene_build, "configs": other_configs, "other_precision": alt, "stress": stress, "stress_mesh": stress_mesh,
+            "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "scene_build": scene_build, "configs": other_configs, "other_precision": alt, "stress": stress, "stress_mesh": stress_mesh, "extensions": extensions,
             "organisations": orgs, "estimators": estimators, "per_rank": per_rank, "kernel_source_hash": src_hash,
         }
         print(json.dumps(result), flush=True)

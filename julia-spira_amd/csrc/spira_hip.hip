@@ -416,14 +416,16 @@ int launch_path_mode(int R, dim3 grid, size_t lds, hipStream_t st, spira::PathAr
     const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
     const bool tri = a.scene.n_triangles != 0;
     const dim3 blk(spira::kBlock);
-    if (ext) {           // extension instantiations (R = 2 only)
+    if (ext) {           // extension instantiations (R = 2 only); like the default kernels, without the LDS triangle scan where the scene has none
         if (spec) {
             a.redo_only = spec == 2 ? 2 : 0;          // (2: every wave will be rendered again, whatever it reports)
-            launch_lds(spira::k_path<T, 2, BVH, true, true, MODE>, grid, blk, lds, st, a);
+            if (tri) launch_lds(spira::k_path<T, 2, BVH, true, true, MODE, true>, grid, blk, lds, st, a);
+            else launch_lds(spira::k_path<T, 2, BVH, true, true, MODE, false>, grid, blk, lds, st, a);
             if (spec == 2) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.redo, 1, (size_t)grid.x * (spira::kBlock / 64), st));
             a.redo_only = 1;
         } else { a.redo = nullptr; a.redo_only = 0; }
-        launch_lds(spira::k_path<T, 2, BVH, true, false, MODE>, grid, blk, lds, st, a);
+        if (tri) launch_lds(spira::k_path<T, 2, BVH, true, false, MODE, true>, grid, blk, lds, st, a);
+        else launch_lds(spira::k_path<T, 2, BVH, true, false, MODE, false>, grid, blk, lds, st, a);
     } else if (R == 2) {
         if (spec) {
             a.redo_only = spec == 2 ? 2 : 0;
@@ -460,7 +462,8 @@ void launch_path_resume(int R, dim3 grid, size_t lds, hipStream_t st, spira::Pat
     const bool ext = (a.rc.flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) != 0;
     const dim3 blk(spira::kBlock);
     a.redo = nullptr; a.redo_only = 0;
-    if (ext) launch_lds(spira::k_path<T, 2, true, true, false, 2>, grid, blk, lds, st, a);
+    if (ext && a.scene.n_triangles) launch_lds(spira::k_path<T, 2, true, true, false, 2, true>, grid, blk, lds, st, a);
+    else if (ext) launch_lds(spira::k_path<T, 2, true, true, false, 2, false>, grid, blk, lds, st, a);
     else if (R == 2 && a.scene.n_triangles) launch_lds(spira::k_path<T, 2, true, false, false, 2, true>, grid, blk, lds, st, a);
     else if (R == 2) launch_lds(spira::k_path<T, 2, true, false, false, 2, false>, grid, blk, lds, st, a);
     else launch_lds(spira::k_path<T, 1, true, false, false, 2>, grid, blk, lds, st, a);

@@ -61,6 +61,19 @@ def scene_s2():
     return dict(spheres5=spheres5, materials8=materials8, triangles10=triangles10, camera12=cam)
 
 
+def scene_s2_glass():
+    """S2 with the mirror sphere turned into glass (ior 1.5), the gold one into tinted glass (ior 1.33) and a glass triangle (ior 1.1): the scene of the
+    SPIRA_EXT_DIELECTRIC / SPIRA_EXT_SPECTRAL extension (include/spira_hip.h: a material with NEGATIVE roughness is a dielectric of index -roughness).
+    No such scene exists in the reference (README.md:10 only names the features): parity unpinned."""
+    s = scene_s2()
+    m = s["materials8"].copy()
+    m[3] = [0.95, 0.95, 0.95, 0, 0, 0, 0.0, -1.5]
+    m[2] = [0.9, 0.7, 0.3, 0, 0, 0, 0.0, -1.33]
+    m[5] = [0.8, 1.0, 0.8, 0, 0, 0, 0.0, -1.1]
+    s["materials8"] = m
+    return s
+
+
 def _wall(center, a, b, material):
     """One oversized triangle covering a whole box wall; its geometric normal normalize(cross(e1,e2))
     (examples/julia-raytracer.jl:105-109) is a x b and must point INTO the box, because semantics A

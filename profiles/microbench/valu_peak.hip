@@ -41,7 +41,42 @@
 #define MOV64(i)  "v_mov_b64 %" #i ", %4\n"
 #define CNDV64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n"
 #define ADDC(i)   "v_addc_co_u32 %" #i ", vcc, %" #i ", %8, vcc\n"
+#define MAX32(i)  "v_max_f32 %" #i ", %" #i ", %8\n"
+#define MAX3F(i)  "v_max3_f32 %" #i ", %" #i ", %8, %9\n"
+#define MIN3U(i)  "v_min3_u32 %" #i ", %" #i ", %8, %8\n"
+#define CVTUB(i)  "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define AND32(i)  "v_and_b32 %" #i ", %" #i ", %8\n"
+#define LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", 3, %8\n"
+#define BFE(i)    "v_bfe_u32 %" #i ", %" #i ", 8, 8\n"
+#define PERM(i)   "v_perm_b32 %" #i ", %" #i ", %8, %8\n"
+#define ADDU(i)   "v_add_u32 %" #i ", %" #i ", %8\n"
+#define MULHI(i)  "v_mul_hi_u32 %" #i ", %" #i ", %8\n"
+#define MAX64(i)  "v_max_f64 %" #i ", %" #i ", %4\n"
+#define CVT3264(i) "v_cvt_f32_f64 %" #i ", %8\n"
+#define SQRT64(i) "v_sqrt_f64 %" #i ", %" #i "\n"
+#define FMAC32(i) "v_fmac_f32 %" #i ", %8, %9\n"
+#define MBCNT(i)  "v_mbcnt_lo_u32_b32 %" #i ", %8, %" #i "\n"
+#define FFBL(i)   "v_ffbl_b32 %" #i ", %" #i "\n"
+#define MAD24(i)  "v_mad_u32_u24 %" #i ", %" #i ", %8, %8\n"
+#define BFI(i)    "v_bfi_b32 %" #i ", %8, %" #i ", %8\n"
 #define REP4(op)  op(0) op(1) op(2) op(3)
+// mixed streams: every other instruction a v_fma_f32 (Float64 rows: v_fma_f64); the partner's MARGINAL cost = pair - the v_fma alone — what the opcode costs inside
+// real code, where a same-opcode stream's serialisation (compares writing one SGPR pair, selects reading it ...) does not occur
+#define PAIR32(X) "v_fma_f32 %0, %0, %16, %17\n" X(8) "v_fma_f32 %1, %1, %16, %17\n" X(9) "v_fma_f32 %2, %2, %16, %17\n" X(10) "v_fma_f32 %3, %3, %16, %17\n" X(11) \
+                  "v_fma_f32 %4, %4, %16, %17\n" X(12) "v_fma_f32 %5, %5, %16, %17\n" X(13) "v_fma_f32 %6, %6, %16, %17\n" X(14) "v_fma_f32 %7, %7, %16, %17\n" X(15)
+#define P_CMPS(i)  "v_cmp_lt_f32_e64 %19, %" #i ", %16\n"
+#define P_CMPV(i)  "v_cmp_lt_f32 vcc, %" #i ", %16\n"
+#define P_CND(i)   "v_cndmask_b32_e64 %" #i ", %" #i ", %18, %19\n"
+#define P_MOV(i)   "v_mov_b32 %" #i ", %18\n"
+#define P_XOR(i)   "v_xor_b32 %" #i ", %" #i ", %18\n"
+#define P_ADDU(i)  "v_add_u32 %" #i ", %" #i ", %18\n"
+#define P_MAX(i)   "v_max_f32 %" #i ", %" #i ", %16\n"
+#define P_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %18\n"
+#define P_CVTUB(i) "v_cvt_f32_ubyte1 %" #i ", %" #i "\n"
+#define P_PERM(i)  "v_perm_b32 %" #i ", %" #i ", %18, %18\n"
+#define P_LSHR(i)  "v_lshrrev_b32 %" #i ", 15, %" #i "\n"
+#define P_FMA(i)   "v_fma_f32 %" #i ", %" #i ", %16, %17\n"
+#define P_RCP(i)   "v_rcp_f32 %" #i ", %" #i "\n"
 
 template <int KIND>
 __global__ void k(float *out, int iters) {
@@ -91,6 +126,38 @@ __global__ void k(float *out, int iters) {
             if (KIND == 31) asm volatile(REP8(CNDV64) : U8 : "v"(m) : "vcc");
             if (KIND == 32) asm volatile("v_cmp_lt_u32 vcc, %0, %8\n" REP8(CND32) : U8 : "v"(m) : "vcc");
             if (KIND == 33) asm volatile("s_mov_b64 vcc, %9\n" REP8(CND32) : U8 : "v"(m), "s"(mask) : "vcc");
+            if (KIND == 40) asm volatile(REP8(MAX32) : A8 : "v"(c1));
+            if (KIND == 41) asm volatile(REP8(MAX3F) : A8 : "v"(c1), "v"(c2));
+            if (KIND == 42) asm volatile(REP8(MIN3U) : U8 : "v"(m));
+            if (KIND == 43) asm volatile(REP8(CVTUB) : U8);
+            if (KIND == 44) asm volatile(REP8(AND32) : U8 : "v"(m));
+            if (KIND == 45) asm volatile(REP8(LSHLOR) : U8 : "v"(m));
+            if (KIND == 46) asm volatile(REP8(BFE) : U8);
+            if (KIND == 47) asm volatile(REP8(PERM) : U8 : "v"(m));
+            if (KIND == 48) asm volatile(REP8(ADDU) : U8 : "v"(m));
+            if (KIND == 49) asm volatile(REP8(MULHI) : U8 : "v"(m));
+            if (KIND == 50) asm volatile(REP4(MAX64) : D4 : "v"(e1));
+            if (KIND == 51) asm volatile(REP8(CVT3264) : A8, "+v"(d0) : );
+            if (KIND == 52) asm volatile(REP4(SQRT64) : D4);
+            if (KIND == 53) asm volatile(REP8(FMAC32) : A8 : "v"(c1), "v"(c2));
+            if (KIND == 54) asm volatile(REP8(MBCNT) : U8 : "v"(m));
+            if (KIND == 55) asm volatile(REP8(FFBL) : U8);
+            if (KIND == 56) asm volatile(REP8(MAD24) : U8 : "v"(m));
+            if (KIND == 57) asm volatile(REP8(BFI) : U8 : "v"(m));
+#define PAIRARGS : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(c1), "v"(c2), "v"(m), "s"(mask)
+            if (KIND == 60) asm volatile(PAIR32(P_CMPS) PAIRARGS);
+            if (KIND == 61) asm volatile(PAIR32(P_CMPV) PAIRARGS : "vcc");
+            if (KIND == 62) asm volatile(PAIR32(P_CND) PAIRARGS);
+            if (KIND == 63) asm volatile(PAIR32(P_MOV) PAIRARGS);
+            if (KIND == 64) asm volatile(PAIR32(P_XOR) PAIRARGS);
+            if (KIND == 65) asm volatile(PAIR32(P_ADDU) PAIRARGS);
+            if (KIND == 66) asm volatile(PAIR32(P_MAX) PAIRARGS);
+            if (KIND == 67) asm volatile(PAIR32(P_MULLO) PAIRARGS);
+            if (KIND == 68) asm volatile(PAIR32(P_CVTUB) PAIRARGS);
+            if (KIND == 69) asm volatile(PAIR32(P_PERM) PAIRARGS);
+            if (KIND == 70) asm volatile(PAIR32(P_LSHR) PAIRARGS);
+            if (KIND == 71) asm volatile(PAIR32(P_FMA) PAIRARGS);
+            if (KIND == 72) asm volatile(PAIR32(P_RCP) PAIRARGS);
             if (KIND == 9) asm volatile(REP8(CND32) : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(m) : "vcc");
         }
     }
@@ -150,5 +217,37 @@ int main() {
     run<27>("v_cvt_f64_u32", 32, d);
     run<28>("v_ldexp_f64", 32, d);
     run<29>("v_mov_b64", 32, d);
+    run<40>("v_max_f32", 64, d);
+    run<41>("v_max3_f32", 64, d);
+    run<42>("v_min3_u32", 64, d);
+    run<43>("v_cvt_f32_ubyte1", 64, d);
+    run<44>("v_and_b32", 64, d);
+    run<45>("v_lshl_or_b32", 64, d);
+    run<46>("v_bfe_u32", 64, d);
+    run<47>("v_perm_b32", 64, d);
+    run<48>("v_add_u32", 64, d);
+    run<49>("v_mul_hi_u32", 64, d);
+    run<50>("v_max_f64", 32, d);
+    run<51>("v_cvt_f32_f64", 64, d);
+    run<52>("v_sqrt_f64", 32, d);
+    run<53>("v_fmac_f32", 64, d);
+    run<54>("v_mbcnt_lo_u32_b32", 64, d);
+    run<55>("v_ffbl_b32", 64, d);
+    run<56>("v_mad_u32_u24", 64, d);
+    run<57>("v_bfi_b32", 64, d);
+    // pairs: cycles per PAIR (one v_fma_f32 + one partner); the partner's marginal cost = this - v_fma_f32's row
+    run<71>("pair:fma+v_fma_f32", 64, d);
+    run<60>("pair:fma+v_cmp_lt_f32_sgpr", 64, d);
+    run<61>("pair:fma+v_cmp_lt_f32_vcc", 64, d);
+    run<62>("pair:fma+v_cndmask_b32", 64, d);
+    run<63>("pair:fma+v_mov_b32", 64, d);
+    run<64>("pair:fma+v_xor_b32", 64, d);
+    run<65>("pair:fma+v_add_u32", 64, d);
+    run<66>("pair:fma+v_max_f32", 64, d);
+    run<67>("pair:fma+v_mul_lo_u32", 64, d);
+    run<68>("pair:fma+v_cvt_f32_ubyte1", 64, d);
+    run<69>("pair:fma+v_perm_b32", 64, d);
+    run<70>("pair:fma+v_lshrrev_b32", 64, d);
+    run<72>("pair:fma+v_rcp_f32", 64, d);
     return 0;
 }

@@ -7,6 +7,7 @@ reports half the bytes of a wide (16 B/lane) coalesced streaming read, so the re
 raw and doubled (the doubled figure applies to the 16-byte packet loads of the ray queues).
 """
 import csv
+import json
 import os
 import sys
 from collections import defaultdict
@@ -158,7 +159,6 @@ def main():
         nl = launches_of("FETCH_SIZE")
         if not nl:
             continue
-        import json
         tot = lambda name: sum(agg[k].get(name, 0) for k in ks)
         rd, wr = tot("FETCH_SIZE") * 1024, tot("WRITE_SIZE") * 1024
         import bench
@@ -198,6 +198,50 @@ def main():
             # (Round 2's priced model — instruction classes x microbenchmarked issue costs — is gone: a third of the instructions belong to no
             # class counter, and pricing them with one average put it above 1.)
             busy = 4.0 * tot("SQ_ACTIVE_INST_VALU") / simd_cycles
+            # ---- the compute side as a fraction.  Two floors for the SIMD cycles per executed VALU instruction of THIS kernel's mix:
+            #   spec   : the data-sheet issue cost of every class — 2 cycles for a 32-bit wave64 instruction (SIMD-32, MI355X_MICROARCH.md; = 157.3 TFLOP/s),
+            #            4 for Float64 FMA / MUL / ADD and 64-bit integer (78.6 TFLOP/s), 8 / 16 for Float32 / Float64 transcendentals — over the DYNAMIC class
+            #            counts of the PMC passes.  issue_util = spec floor / measured cycles per instruction: a fraction in (0, 1] by construction.
+            #   priced : the same counts priced with the issue costs MEASURED on this chip (profiles/microbench/valu_peak.hip: a class's opcodes as the kernel's ISA
+            #            holds them, profiles/isa_cost.json; an opcode costs the lower of its own stream and its marginal cost beside v_fma_f32).  What a perfectly
+            #            scheduled, never-stalled wave mix of this kernel would need on the real issue port; issue_util_priced = priced / measured.
+            # flops_frac: Float64 / Float32 (2 FMA + MUL + ADD) lane-operations (wave-instructions x 64 x the measured lane utilisation) over 78.6 / 157.3 TFLOP/s.
+            SPEC = {"fma_f32": 2, "mul_f32": 2, "add_f32": 2, "trans_f32": 8, "int32": 2, "cvt": 2, "fma_f64": 4, "mul_f64": 4, "add_f64": 4, "trans_f64": 16, "int64": 4, "other": 2}
+            lane_util = tot("SQ_THREAD_CYCLES_VALU") / max(1.0, 64 * tot("SQ_ACTIVE_INST_VALU"))
+            compute = None
+            if mix and "fma_f32" in mix:
+                is_f64 = "double" in "".join(ks)
+                # `other` in a Float64 kernel holds 64-bit moves / compares / min-max / the division helpers: priced as the kernel's ISA has them (isa_cost.json), spec floor 2
+                isa = {}
+                try:
+                    isa_all = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "isa_cost.json")))["kernels"]
+                    wsum = 0.0
+                    for k in ks:                      # the instantiations of this run, weighted by their dynamic VALU counts
+                        w_k = agg[k].get("SQ_INSTS_VALU", 0.0)
+                        if k in isa_all and w_k:
+                            for cls, cst in isa_all[k]["class_cost"].items():
+                                isa[cls] = isa.get(cls, 0.0) + w_k * cst
+                            wsum += w_k
+                    isa = {c: v / wsum for c, v in isa.items()} if wsum else {}
+                except (OSError, KeyError, ValueError):
+                    isa = {}
+                spec_c = sum(mix.get(c, 0.0) * SPEC[c] for c in SPEC)
+                priced_c = sum(mix.get(c, 0.0) * isa.get(c, SPEC[c] * 1.5) for c in SPEC) if isa else None
+                measured_c = simd_cycles / n_inst
+                secs = wall_ns * 1e-9
+                f64_flops = (2 * mix.get("fma_f64", 0) + mix.get("mul_f64", 0) + mix.get("add_f64", 0)) * n_inst * 64 * lane_util
+                f32_flops = (2 * mix.get("fma_f32", 0) + mix.get("mul_f32", 0) + mix.get("add_f32", 0)) * n_inst * 64 * lane_util
+                arith = sum(mix.get(c, 0.0) for c in ("fma_f32", "mul_f32", "add_f32", "trans_f32", "fma_f64", "mul_f64", "add_f64", "trans_f64"))
+                compute = {"min_cycles_per_inst_spec": round(spec_c, 3), "issue_util": round(spec_c / measured_c, 4),
+                           "min_cycles_per_inst_priced": round(priced_c, 3) if priced_c else None, "issue_util_priced": round(priced_c / measured_c, 4) if priced_c else None,
+                           "flops_frac": round(f64_flops / secs / 78.6e12 + f32_flops / secs / 157.3e12, 4),
+                           "tflops": {"f64": round(f64_flops / secs / 1e12, 3), "f32": round(f32_flops / secs / 1e12, 3)},
+                           "non_arithmetic_share": round(1.0 - arith, 4), "float64_kernel": is_f64,
+                           "what": "issue_util = (dynamic class counts x data-sheet issue cycles: 2 per 32-bit, 4 per 64-bit, 8 / 16 per transcendental wave64 instruction) / measured SIMD cycles "
+                                   "per VALU instruction: the share of the VALU issue port this mix needs at best, in (0, 1]; issue_util_priced = the same with the issue costs measured on this "
+                                   "chip (profiles/isa_cost.json, r04_valu_peak.txt); flops_frac = (2 FMA + MUL + ADD) lane-operations over 78.6 (f64) / 157.3 (f32) TFLOP/s; "
+                                   "non_arithmetic_share = instructions that are no FMA / MUL / ADD / transcendental (integer, conversions, moves, compares, selects, division helpers)"}
+            out["compute"] = compute
             out["valu"] = {"issue_slots": round(2.0 * n_inst / simd_cycles, 4), "valubusy_rocprof": round(busy, 4), "simd_cycles_per_valu_inst": round(simd_cycles / n_inst, 3),
                            "effective_clock_GHz": round(tot("GRBM_GUI_ACTIVE") / 8 / max(wall_ns, 1.0), 3),
                            "lane_utilisation": round(tot("SQ_THREAD_CYCLES_VALU") / max(1.0, 64 * tot("SQ_ACTIVE_INST_VALU")), 4),

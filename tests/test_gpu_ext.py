@@ -10,15 +10,7 @@ from test_gpu_parity import _args, _close, _counts, random_scene
 pytestmark = pytest.mark.gpu
 
 
-def glass_scene():
-    """S2 with the mirror sphere turned into glass (ior 1.5), the gold one into tinted glass (ior 1.33), and a glass triangle."""
-    s = scenes.scene_s2()
-    m = s["materials8"].copy()
-    m[3] = [0.95, 0.95, 0.95, 0, 0, 0, 0.0, -1.5]
-    m[2] = [0.9, 0.7, 0.3, 0, 0, 0, 0.0, -1.33]
-    m[5] = [0.8, 1.0, 0.8, 0, 0, 0, 0.0, -1.1]
-    s["materials8"] = m
-    return s
+glass_scene = scenes.scene_s2_glass      # S2 with two glass spheres and a glass triangle
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
