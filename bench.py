@@ -194,7 +194,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=None, help="override the configuration's spp")
     ap.add_argument("--depth", type=int, default=None)
-    ap.add_argument("--scene", default=None, choices=["s1", "s2", "s3", "s4", "s5"])
+    ap.add_argument("--scene", default=None, choices=["s1", "s2", "s3", "s4", "s5", "s2g"])
+    ap.add_argument("--ext", default=None, choices=["spectral", "dielectric", "both"], help="SPIRA_EXT_* extension flags for the timed workload (parity unpinned; profiles/)")
     ap.add_argument("--kernel", default="wavefront", choices=["wavefront", "bounce", "mega"],
                     help="wavefront = persistent hit-queue kernel (default); bounce = round-1 per-bounce launches; mega = one lane per path")
     ap.add_argument("--prec", default="f64", choices=["f32", "f64"],
@@ -257,7 +258,8 @@ def main():
         return sc, (ns, nm, nt)
 
     sc, counts = workload(scene_name)
-    params = B.make_params(W, H, spp_total, depth, *counts, flags=kflags[args.kernel] | B.POST_NONE, seed=seed, **tile)
+    ext_flags = {None: 0, "spectral": B.EXT_SPECTRAL, "dielectric": B.EXT_DIELECTRIC, "both": B.EXT_SPECTRAL | B.EXT_DIELECTRIC}[args.ext]
+    params = B.make_params(W, H, spp_total, depth, *counts, flags=kflags[args.kernel] | B.POST_NONE | ext_flags, seed=seed, **tile)
     tdt = {"f32": torch.float32, "f64": torch.float64}
     out = torch.empty((3, rows, W), dtype=tdt[args.prec], device="cuda")
 
@@ -365,7 +367,7 @@ def main():
     if rank == 0:
         assert bool(torch.isfinite(img).all()), "non-finite pixels"
         if args.kernel == "wavefront":
-            roof = roofline_record(c_timed, args.prec, args.kernel, scene_name, pmc_shape, src_hash)
+            roof = roofline_record(c_timed, args.prec, args.kernel, scene_name + ("_ext" if ext_flags else ""), pmc_shape, src_hash)
         elif args.kernel == "bounce":
             roof = side_run(scene_name, "bounce", args.prec, reps=1)[2]
         else:
