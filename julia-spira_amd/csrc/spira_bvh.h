@@ -116,11 +116,18 @@ class HostPool {
     void run(size_t n_jobs, const std::function<void(size_t)> &fn) {
         if (n_jobs == 0) return;
         if (workers_.empty() || n_jobs == 1) { for (size_t j = 0; j < n_jobs; ++j) fn(j); return; }
+        // 1. CLOSE the claim word before anything of the job descriptor changes: a worker that is late for the previous generation (it saw that
+        //    generation, was descheduled, and only now reads fn / n / next) must fail its tag check — with the old tag still in `next_` it would pair
+        //    the NEW n with the OLD tag, claim an index the old generation never had, and run a job nobody waits for (found by a stress run: one build
+        //    in ~40 hung with done == n + 1, or crashed in a dead std::function)
+        const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
+        next_.store((g << 32) | 0xFFFFFFFFull, std::memory_order_seq_cst);      // tag g, index beyond any n: nothing can be claimed
+        // 2. the descriptor of generation g
         fn_.store(&fn, std::memory_order_relaxed); n_jobs_.store(n_jobs, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
-        const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
-        next_.store(g << 32, std::memory_order_relaxed);
-        gen_.store(g);                                         // publishes the job (seq_cst: ordered against the sleepers' count, below)
+        // 3. open it, publish it
+        next_.store(g << 32, std::memory_order_release);
+        gen_.store(g);                                         // (seq_cst: ordered against the sleepers' count, below)
         if (sleepers_.load() != 0) { { std::lock_guard<std::mutex> lk(mu_); } cv_.notify_all(); }
         work(g);
         // the call ends when every JOB is done, not when every worker has looked in: a worker the system has not scheduled yet holds nobody up,
@@ -132,13 +139,15 @@ class HostPool {
     // jobs are claimed through one word {generation, next index}: a claim that succeeds belongs to the generation the claimer saw, which is
     // therefore still running (run() waits for that job), so `fn` is alive while it executes
     void work(uint64_t g) {
-        const std::function<void(size_t)> *fn = fn_.load(std::memory_order_relaxed);
-        const size_t n = n_jobs_.load(std::memory_order_relaxed);
+        // (acquire loads, in this order: the descriptor is read BEFORE the claim word, so a claim word that still carries this generation's tag
+        //  proves the descriptor read is this generation's too — run() closes the word before it rewrites the descriptor)
+        const std::function<void(size_t)> *fn = fn_.load(std::memory_order_acquire);
+        const size_t n = n_jobs_.load(std::memory_order_acquire);
         for (;;) {
-            uint64_t cur = next_.load(std::memory_order_relaxed);
+            uint64_t cur = next_.load(std::memory_order_acquire);
             for (;;) {
                 if ((cur >> 32) != (g & 0xFFFFFFFFull) || (cur & 0xFFFFFFFFull) >= n) return;
-                if (next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_relaxed)) break;
+                if (next_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire)) break;
             }
             (*fn)((size_t)(cur & 0xFFFFFFFFull));
             done_.fetch_add(1, std::memory_order_release);

@@ -234,6 +234,28 @@ template <class T> static void determinism(uint32_t n, uint32_t seed) {
     std::printf("determinism %-6s n=%-6u slots=%-6u depth=%d: 1 == 2 == 3 == 8 == 13 threads\n", sizeof(T) == 4 ? "f32" : "f64", n, fr1.n_slots, fr1.depth);
 }
 
+// The build's thread pool on its own: thousands of short generations of varying job counts (serial one-job runs and sleepy gaps in between, more threads than
+// cores), every job of every generation executed exactly once.  (Round 4: a worker that was late for one generation could pair the next generation's job count
+// with the old claim word and run a job nobody waited for — one build in ~40 hung or crashed.  run() now closes the claim word before it rewrites the descriptor.)
+static void pool_stress(int reps, int runs) {
+    for (int rep = 0; rep < reps; ++rep) {
+        spira::HostPool pool(16);
+        for (int r = 0; r < runs; ++r) {
+            const size_t n = 1 + (size_t)((r * 7 + rep) % 41);
+            std::vector<std::atomic<int>> hits(n);
+            for (auto &h : hits) h = 0;
+            std::atomic<int> total{0};
+            pool.run(n, [&](size_t j) { volatile double x = 1; for (int i = 0; i < 100 + (int)(j % 5) * 200; ++i) x = x * 1.000001 + 1e-9; if (j < n) hits[j]++; total++; });
+            bool ok = total == (int)n;
+            for (size_t j = 0; j < n; ++j) ok = ok && hits[j] == 1;
+            CHECK(ok);
+            if (!ok) return;
+            if (r % 50 == 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+    }
+    std::printf("pool stress: %d pools x %d generations, every job exactly once\n", reps, runs);
+}
+
 static void fastdiv_checks() {
     std::mt19937 rng(7);
     const uint32_t ds[] = {1, 2, 3, 5, 7, 8, 64, 1000, 1920, 2073600, 132710400, 0x7FFFFFFF, 0x80000000u, 0xFFFFFFFFu};
@@ -320,6 +342,7 @@ int main(int argc, char **argv) {
     determinism<double>(40000, 22);
     determinism<float>(700, 23);
     determinism<double>(5, 24);
+    pool_stress(argc > 1 ? 12 : 120, 300);
     if (argc > 1 && std::strcmp(argv[1], "determinism") == 0) {      // (the ThreadSanitizer build runs this part only)
         if (g_fail) { std::fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
         std::printf("host sanitize harness: all checks passed\n");
