@@ -415,7 +415,8 @@ def main():
                                "avg_launch_ms": oroof and oroof["avg_launch_ms"], "launches": oroof and oroof["launches"]}
             if scene_name in ("s1",) and args.config in ("c3", "c4"):        # the reference's other estimators on the same frame (sphere scenes only)
                 estimators = {}
-                for name, sem, k in (("metal_wavefront", B.SEM_METAL, "wavefront"), ("metal_one_lane_per_pixel", B.SEM_METAL, "mega"), ("cpu_one_lane_per_path", B.SEM_CPU, "mega")):
+                for name, sem, k in (("metal_wavefront", B.SEM_METAL, "wavefront"), ("metal_one_lane_per_pixel", B.SEM_METAL, "mega"), ("cpu_one_lane_per_path", B.SEM_CPU, "mega"),
+                                     ("hybrid_as_written", B.SEM_HYBRID, "mega")):      # render_hybrid_gpu's own estimator: (max_depth + 1) launches per sample, a fidelity path
                     v, ms, eroof = side_run(scene_name, k, args.prec, sem=sem)
                     estimators[name] = {"value": round(v, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3), "dtype": args.prec, "roofline": eroof}
         # ---- the other BASELINE configurations that fit one GPU (N=1 only): configs[3] = 1080p spp 256 depth 8 on S3 (4 passes of 64 sample slots; on

@@ -34,9 +34,10 @@
  *   spira_accumulate_f32/_f64 (+ _device_)
  *       the progressive contract of src/spira_path_trace_kernel.metal:143-145,:252-268
  *       (current_sample_index, persisted rng_states, output += L), which no reference host code drives.
- *   flags & SPIRA_SEM_MASK selects which of the reference's estimators runs:
+ *   flags & SPIRA_SEM_MASK selects which of the reference's FOUR estimators runs:
  *       ray_color (examples/julia-raytracer.jl:328-367, default), trace_ray of render_with_cpu
- *       (src/spira-metal-optimized.jl:1351-1412), path_trace (src/spira_path_trace_kernel.metal:140-269).
+ *       (src/spira-metal-optimized.jl:1351-1412), path_trace (src/spira_path_trace_kernel.metal:140-269), render_hybrid_gpu's own
+ *       (src/spira-metal-optimized.jl:1228-1343).
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a
  * negative SPIRA_E_* code otherwise; nothing throws, aborts or calls back across the ABI;
@@ -75,6 +76,12 @@ extern "C" {
 #define SPIRA_SEM_A             0x00000000u  /* examples/julia-raytracer.jl ray_color :328-367 (graded oracle) */
 #define SPIRA_SEM_CPU           0x00000001u  /* render_with_cpu trace_ray src/spira-metal-optimized.jl:1351-1412 */
 #define SPIRA_SEM_METAL         0x00000002u  /* path_trace src/spira_path_trace_kernel.metal:140-269 */
+#define SPIRA_SEM_HYBRID        0x00000003u  /* render_hybrid_gpu src/spira-metal-optimized.jl:1228-1343 AS WRITTEN — what render() runs on a Metal / CUDA machine:
+                                                the whole image in lock step (K3 raygen with per-pixel xorshift32 :610-697, K4 :700-799, the image-wide
+                                                "nothing hit: end the sample" :1303, K5 scatter :862-989, contribution halved per depth :1328, K6 shade of
+                                                the LAST bounce only :1071-1105, K7 ACES + sqrt per sample :1128-1144, K8 :1055-1068).  Restated, not
+                                                repaired.  Spheres only, whole images only (rows == 0), no accumulate entry; out_hdr = out_img = the
+                                                reference's (already tone-mapped) image; SPIRA_POST_* and SPIRA_KERNEL_* are ignored. */
 /* kernel organisation */
 #define SPIRA_KERNEL_MASK       0x000000F0u
 #define SPIRA_KERNEL_DEFAULT    0x00000000u  /* the library's choice = the fastest organisation measured for the estimator:

@@ -2758,6 +2758,164 @@ template <class T> __host__ __device__ inline T aces1(T x) {
 }
 __host__ __device__ inline float sqrt_any(float x) { return __builtin_sqrtf(x); }
 __host__ __device__ inline double sqrt_any(double x) { return __builtin_sqrt(x); }
+// ====================================================================== SPIRA_SEM_HYBRID: render_hybrid_gpu as written
+// The estimator of src/spira-metal-optimized.jl:1228-1343 (what render() executes on a Metal / CUDA machine), statement by statement like the oracle's
+// oracle_render_hybrid: the whole image advances in lock step, and one condition is image-wide — `if sum(hit_results[:, 1]) == 0 break` (:1303) ends a
+// sample for EVERY pixel when no ray of the image hit anything at this depth.  So a sample is max_depth + 1 launches of one lane per pixel:
+//   phase 0                 K3 raygen (:610-697, per-pixel xorshift32 :412-426) + K4 intersection of depth 1 (:700-799)
+//   phase p = 1..max-1      if any ray hit at depth p: K5 scatter of depth p (:862-989), then K4 of depth p + 1
+//   phase max               if any ray hit at depth max: K5, then K6 shade (:1071-1105) with contribution 0.5^max (:1328), K7 tone map (:1128-1144), sum
+// `flags[(sample - 1) * (max_depth + 1) + depth]` is set by any lane that hits at that depth (a plain store of 1: no atomic needed) and read by the next
+// launch; a depth nobody reached stays 0, so a sample that broke stays broken.  The reference relaunches ~12 kernels per sphere per depth with host
+// round trips; here a 1080p frame at spp 64, depth 8 is 576 launches back to back on one stream.  Not a performance path: a fidelity path.
+template <class T> struct HybridPx { Vec<T> d, o, pt, n; };      // per-pixel ray state between launches (SoA planes in `state`: 12 values) + mat, rng
+template <class T> struct HybridArgs {
+    SceneGlobal<T> scene;
+    RenderConst<T> rc;
+    T *state;                // [12][P]: d.xyz, o.xyz, pt.xyz, n.xyz
+    uint32_t *mat;           // [P] material (1-based) of the hit of the last intersection, 0 = none
+    uint32_t *rng;           // [P] xorshift32 states
+    Pack4<T> *accum;         // [P] sums of the tone-mapped samples, in OUTPUT row order
+    uint32_t *flags;         // [spp][max_depth + 1]
+    Stats *stats;
+    uint32_t sample;         // 1-based (:1275)
+    uint32_t phase;          // 0 .. max_depth
+};
+__device__ __forceinline__ uint32_t xorshift32_step(uint32_t s) { s ^= s << 13; s ^= s >> 17; s ^= s << 5; return s; }      // :412-417
+template <class T> __device__ __forceinline__ T xs_uniform(uint32_t s) { return (T)(float)((double)s / 4294967295.0); }       // Float32(state / typemax(UInt32)), :420-426
+template <class T> __device__ __forceinline__ T aces_sqrt(T x) {                                                               // :1133-1143
+    const T a = (T)2.51f, b = (T)0.03f, c = (T)2.43f, d = (T)0.59f, e = (T)0.14f;
+    T r = (x * (a * x + b)) / (x * (c * x + d) + e);
+    r = r < (T)0 ? (T)0 : (r > (T)1 ? (T)1 : r);
+    return sqrt_rn(r);
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void k_hybrid(const HybridArgs<T> a) {
+    extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+    const RenderConst<T> &rc = a.rc;
+    const uint32_t P = rc.width * rc.height, D = rc.max_depth;
+    uint32_t *fl = a.flags + (size_t)(a.sample - 1) * (D + 1);
+    if (a.phase > 0 && fl[a.phase] == 0) return;                  // the image-wide break (:1303), or a sample that broke earlier (workgroup-uniform: ahead of the barrier)
+    const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);
+    unsigned long long nseg = 0;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < P; k += gridDim.x * kBlock) {
+        Vec<T> o, d;
+        uint32_t st = a.rng[k];
+        if (a.phase == 0) {
+            // ---- K3
+            st = xorshift32_step(st + a.sample);                                                  // :632
+            st = xorshift32_step(st); const T rand1 = xs_uniform<T>(st);                          // :635-636
+            st = xorshift32_step(st); const T rand2 = xs_uniform<T>(st);                          // :637-638
+            const uint32_t row = k / rc.width, col = k - row * rc.width;                          // :651-652
+            const T u_center = (T)col / (T)(rc.width - 1), v_center = (T)row / (T)(rc.height - 1);      // :656-657
+            const T pw = (T)1.0 / (T)(rc.width - 1), ph = (T)1.0 / (T)(rc.height - 1);            // :669-670
+            const T u = u_center + (rand1 - (T)0.5) * (T)0.5 * pw;                                // :672
+            const T v = v_center + (rand2 - (T)0.5) * (T)0.5 * ph;                                // :673
+            const T dx = rc.cam_llc.x + u * rc.cam_hor.x + v * rc.cam_ver.x - rc.cam_origin.x;    // :676
+            const T dy = rc.cam_llc.y + u * rc.cam_hor.y + v * rc.cam_ver.y - rc.cam_origin.y;
+            const T dz = rc.cam_llc.z + u * rc.cam_hor.z + v * rc.cam_ver.z - rc.cam_origin.z;
+            const T len_sq = dx * dx + dy * dy + dz * dz;                                         // :681
+            const T inv_len = len_sq > (T)0 ? sqrt_rn((T)1.0 / len_sq) : (T)0;                    // :682
+            o = rc.cam_origin;
+            d = mk<T>(dx * inv_len, dy * inv_len, dz * inv_len);                                  // :689-691
+        } else {
+            // ---- K5 on the hit of depth `phase`
+            d = mk<T>(a.state[k], a.state[(size_t)P + k], a.state[2 * (size_t)P + k]);
+            const Vec<T> pt = mk<T>(a.state[6 * (size_t)P + k], a.state[7 * (size_t)P + k], a.state[8 * (size_t)P + k]);
+            const uint32_t mat = a.mat[k];
+            o = pt;                                                                               // :883-885: (0, 0, 0) for a ray that missed
+            if (mat) {                                                                            // :888
+                const Pack4<T> ma = sc.mat[2 * (mat - 1)], mb = sc.mat[2 * (mat - 1) + 1];
+                const T metallic = ma.w, roughness = mb.w;                                        // :892-893
+                const T nx = a.state[9 * (size_t)P + k], ny = a.state[10 * (size_t)P + k], nz = a.state[11 * (size_t)P + k];
+                const T dot_prod = d.x * nx + d.y * ny + d.z * nz;                                // :904
+                if (metallic > (T)0) {                                                            // :907
+                    T rx = d.x - (T)2.0 * dot_prod * nx, ry = d.y - (T)2.0 * dot_prod * ny, rz = d.z - (T)2.0 * dot_prod * nz;      // :908-910
+                    if (roughness > (T)0) {                                                       // :912
+                        st = xorshift32_step(st); T r1 = xs_uniform<T>(st) - (T)0.5;              // :914-925
+                        st = xorshift32_step(st); T r2 = xs_uniform<T>(st) - (T)0.5;
+                        st = xorshift32_step(st); T r3 = xs_uniform<T>(st) - (T)0.5;
+                        const T nl = sqrt_rn(r1 * r1 + r2 * r2 + r3 * r3);                        // :927
+                        if (nl > (T)1e-5f) { const T il = (T)1.0 / nl; r1 *= il; r2 *= il; r3 *= il; }      // :928-933
+                        rx += roughness * r1; ry += roughness * r2; rz += roughness * r3;         // :935-937
+                        const T il = (T)1.0 / sqrt_rn(rx * rx + ry * ry + rz * rz);               // :939
+                        rx *= il; ry *= il; rz *= il;
+                    }
+                    d = mk<T>(rx, ry, rz);                                                        // :944-946
+                } else {                                                                          // :947
+                    T lx = 0, ly = 0, lz = 0;
+                    for (int tries = 0; tries < 64; ++tries) {                                    // while true, :950-963 (bounded like the oracle)
+                        st = xorshift32_step(st); const T r1 = xs_uniform<T>(st);
+                        st = xorshift32_step(st); const T r2 = xs_uniform<T>(st);
+                        st = xorshift32_step(st); const T r3 = xs_uniform<T>(st);
+                        lx = r1 * (T)2.0 - (T)1.0; ly = r2 * (T)2.0 - (T)1.0; lz = r3 * (T)2.0 - (T)1.0;
+                        if (lx * lx + ly * ly + lz * lz <= (T)1.0) break;
+                        if (tries == 63) { lx = 0; ly = 0; lz = 0; }
+                    }
+                    const T ddx = nx + lx, ddy = ny + ly, ddz = nz + lz;                          // :966-968
+                    const T ls = ddx * ddx + ddy * ddy + ddz * ddz;                               // :970
+                    if (ls < (T)1e-5f) d = mk<T>(nx, ny, nz);                                     // :971-974
+                    else { const T il = (T)1.0 / sqrt_rn(ls); d = mk<T>(ddx * il, ddy * il, ddz * il); }      // :976-979
+                }
+            }
+            if (a.phase == D) {
+                // ---- K6 with the hit of depth max and the NEW direction, contribution = 0.5^max (:1328); K7; the running sum (:1334)
+                T contribution = (T)1.0;
+                for (uint32_t i = 0; i < D; ++i) contribution *= (T)0.5;
+                T cr, cg, cb;
+                if (mat) {                                                                        // :1084-1096
+                    const Pack4<T> ma = sc.mat[2 * (mat - 1)], mb = sc.mat[2 * (mat - 1) + 1];
+                    cr = ma.x * contribution + mb.x; cg = ma.y * contribution + mb.y; cb = ma.z * contribution + mb.z;
+                } else {                                                                          // :1097-1102
+                    const T t = (T)0.5 * (d.y + (T)1.0);
+                    cr = ((T)1.0 - t) + t * (T)0.5; cg = ((T)1.0 - t) + t * (T)0.7f; cb = ((T)1.0 - t) + t * (T)1.0;
+                }
+                const uint32_t row = k / rc.width, col = k - row * rc.width;
+                const uint32_t y = (rc.flags & 0x00001000u /*SPIRA_ROWS_BOTTOM_UP*/) ? row : rc.height - 1 - row;      // the row flip of :1177-1188
+                Pack4<T> acc = a.accum[(size_t)y * rc.width + col];
+                acc.x += aces_sqrt<T>(cr); acc.y += aces_sqrt<T>(cg); acc.z += aces_sqrt<T>(cb);
+                a.accum[(size_t)y * rc.width + col] = acc;
+                a.rng[k] = st;
+                continue;
+            }
+        }
+        // ---- K4: the intersection of depth phase + 1
+        uint32_t mat = 0; T best = (T)1e20f;                                                      // :713-715
+        Vec<T> pt = mk<T>(0, 0, 0), nn = mk<T>(0, 0, 0);                                          // :718-719
+        for (uint32_t s = 0; s < sc.n_spheres; ++s) {                                             // :724
+            const T cx = a.scene.spheres5[5 * (size_t)s], cy = a.scene.spheres5[5 * (size_t)s + 1], cz = a.scene.spheres5[5 * (size_t)s + 2], rad = a.scene.spheres5[5 * (size_t)s + 3];
+            const T ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;                               // :735-737
+            const T aa = d.x * d.x + d.y * d.y + d.z * d.z;                                       // :740
+            const T half_b = ocx * d.x + ocy * d.y + ocz * d.z;                                   // :741-743
+            const T c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;                            // :744
+            const T disc = half_b * half_b - aa * c;                                              // :747
+            if (!(disc > (T)0)) continue;                                                         // :750
+            const T sq = sqrt_rn(disc);                                                           // :759
+            const T t1 = (-half_b - sq) / aa, t2 = (-half_b + sq) / aa;                           // :760-761
+            const T t = t1 > (T)0.001f ? t1 : t2;                                                 // :764
+            if (t <= (T)0.001f || t >= best) continue;                                            // :767
+            best = t; mat = (uint32_t)a.scene.spheres5[5 * (size_t)s + 4];                        // :772-774
+            pt = mk<T>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);                              // :777-779
+            const T nx = pt.x - cx, ny = pt.y - cy, nz = pt.z - cz;                               // :782-784
+            const T il = (T)1.0 / sqrt_rn(nx * nx + ny * ny + nz * nz);                           // :787
+            nn = mk<T>(nx * il, ny * il, nz * il);                                                // :788-790
+        }
+        ++nseg;
+        if (mat) fl[a.phase + 1] = 1u;                                                            // some ray of the image hit at this depth
+        a.state[k] = d.x; a.state[(size_t)P + k] = d.y; a.state[2 * (size_t)P + k] = d.z;
+        a.state[6 * (size_t)P + k] = pt.x; a.state[7 * (size_t)P + k] = pt.y; a.state[8 * (size_t)P + k] = pt.z;
+        a.state[9 * (size_t)P + k] = nn.x; a.state[10 * (size_t)P + k] = nn.y; a.state[11 * (size_t)P + k] = nn.z;
+        a.mat[k] = mat;
+        a.rng[k] = st;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) nseg += __shfl_down(nseg, sft);
+    if ((threadIdx.x & 63) == 0 && nseg) atomicAdd(&a.stats->segments, nseg);
+}
+// the per-pixel xorshift32 states of a render: rand(UInt32, width * height) in the reference (:1258), derived from the seed here (like SPIRA_SEM_METAL's)
+static __global__ void k_hybrid_init(uint32_t *rng, uint32_t n, uint32_t sA, uint32_t sB) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) rng[k] = mix32(mix32(sA + k) ^ sB);
+}
+
 template <class T> __host__ __device__ inline T post1(T x, uint32_t post) {
     switch (post) {
     case 0x000u: return aces1<T>(x);

@@ -102,6 +102,7 @@ struct Ctx {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], mesh_list, mesh_count, redo, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf hyb_state, hyb_mat, hyb_flags;          // SPIRA_SEM_HYBRID: per-pixel ray state between its launches
     DevBuf spd32, spd64;                          // SPIRA_EXT_SPECTRAL: the SPD table, uploaded once per precision
     DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
     SceneStore scene;                         // the scene of the current call (host-array entry points)
@@ -216,8 +217,10 @@ int validate_params(const void *camera12, const spira_params *p, uint32_t nt, ui
     if (p->spp < 1 || p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "spp out of range [1, 2^24]");
     if (p->max_depth > SPIRA_MAX_DEPTH) return fail(SPIRA_E_LIMIT, "max_depth > 255");
     const uint32_t sem = p->flags & SPIRA_SEM_MASK;
-    if (sem != SPIRA_SEM_A && sem != SPIRA_SEM_CPU && sem != SPIRA_SEM_METAL) return fail(SPIRA_E_UNSUPPORTED, "unknown integrator semantics");
-    if (sem != SPIRA_SEM_A && nt) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_CPU / SPIRA_SEM_METAL are sphere-only, like their sources");
+    if (sem != SPIRA_SEM_A && sem != SPIRA_SEM_CPU && sem != SPIRA_SEM_METAL && sem != SPIRA_SEM_HYBRID) return fail(SPIRA_E_UNSUPPORTED, "unknown integrator semantics");
+    if (sem != SPIRA_SEM_A && nt) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_CPU / SPIRA_SEM_METAL / SPIRA_SEM_HYBRID are sphere-only, like their sources");
+    if (sem == SPIRA_SEM_HYBRID && p->rows != 0)
+        return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_HYBRID renders whole images only (the reference ends a sample when no ray of the IMAGE hits anything): rows must be 0");
     uint32_t kern = p->flags & SPIRA_KERNEL_MASK;
     if (kern != SPIRA_KERNEL_DEFAULT && kern != SPIRA_KERNEL_WAVEFRONT && kern != SPIRA_KERNEL_MEGA && kern != SPIRA_KERNEL_BOUNCE) return fail(SPIRA_E_UNSUPPORTED, "unknown kernel organisation");
     if (p->flags & (SPIRA_EXT_DIELECTRIC | SPIRA_EXT_SPECTRAL)) {
@@ -666,6 +669,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     lap("validate");
     if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
     if (progressive && (uint64_t)sample0 + p->spp > SPIRA_MAX_SPP) return fail(SPIRA_E_LIMIT, "sample0 + spp exceeds 2^24");
+    if (progressive && (p->flags & SPIRA_SEM_MASK) == SPIRA_SEM_HYBRID) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_HYBRID has no accumulate entry (its image is a mean of tone-mapped samples)");
     if (progressive && (p->flags & SPIRA_SEM_MASK) == SPIRA_SEM_METAL && sample0 > 0 && !rng_states)
         return fail(SPIRA_E_INVALID, "SPIRA_SEM_METAL with sample0 > 0 needs rng_states (the LCG states the previous call left); "
                                      "without them every call would replay the samples of the first");
@@ -743,7 +747,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 if (int rc = c.qB[i].ensure(q_rays * sizeof(P4))) return rc;
                 if (int rc = c.qC[i].ensure(q_rays * sizeof(P2))) return rc;
             }
-        if (int rc = c.L.ensure(batch * sizeof(spira::Pack3<T>))) return rc;
+        if (sem != SPIRA_SEM_HYBRID) { if (int rc = c.L.ensure(batch * sizeof(spira::Pack3<T>))) return rc; }
         // per-wave survivor counts exist in the per-bounce organisation only; statistics: one row per wave per launch
         if (per_bounce) { if (int rc = c.counts.ensure((size_t)(p->max_depth + 2) * G_max * wpb * sizeof(uint32_t))) return rc; }
         if (int rc = c.blkstats.ensure((size_t)(per_bounce ? p->max_depth + 1 : 1) * G_max * wpb * 4 * sizeof(uint32_t))) return rc;
@@ -807,6 +811,31 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
 
     if (p->max_depth == 0) {
         if (!progressive) HIP_TRY(hipMemsetAsync(c.accum.p, 0, tile_pixels * sizeof(P4), st));   // depth <= 0 -> Vec3(0,0,0), :330
+    } else if (sem == SPIRA_SEM_HYBRID) {
+        // render_hybrid_gpu as written (spira_device.h, k_hybrid): the whole image in lock step, max_depth + 1 launches per sample, all on this stream
+        const uint64_t P = tile_pixels;
+        if (P > 0xFFFFFFFFull / 2) return fail(SPIRA_E_LIMIT, "image too large for SPIRA_SEM_HYBRID");
+        if (int rc = c.hyb_state.ensure(12 * P * sizeof(T))) return rc;
+        if (int rc = c.hyb_mat.ensure(P * sizeof(uint32_t))) return rc;
+        if (int rc = c.rng.ensure(P * sizeof(uint32_t))) return rc;
+        const size_t n_flags = (size_t)p->spp * (p->max_depth + 1);
+        if (int rc = c.hyb_flags.ensure(n_flags * sizeof(uint32_t))) return rc;
+        HIP_TRY(hipMemsetAsync(c.hyb_flags.p, 0, n_flags * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(c.accum.p, 0, P * sizeof(P4), st));
+        HIP_TRY(hipMemsetAsync(c.hyb_mat.p, 0, P * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(c.hyb_state.p, 0, 12 * P * sizeof(T), st));
+        const uint32_t hblocks = std::min<uint32_t>((uint32_t)((P + spira::kBlock - 1) / spira::kBlock), max_blocks);
+        hipLaunchKernelGGL(spira::k_hybrid_init, dim3(hblocks), dim3(spira::kBlock), 0, st, (uint32_t *)c.rng.p, (uint32_t)P, a.rc.sA, a.rc.sB);
+        spira::HybridArgs<T> ha{};
+        ha.scene = a.scene; ha.rc = a.rc; ha.state = (T *)c.hyb_state.p; ha.mat = (uint32_t *)c.hyb_mat.p; ha.rng = (uint32_t *)c.rng.p;
+        ha.accum = (P4 *)c.accum.p; ha.flags = (uint32_t *)c.hyb_flags.p; ha.stats = (spira::Stats *)c.stats.p;
+        for (uint32_t smp = 1; smp <= p->spp; ++smp)
+            for (uint32_t ph = 0; ph <= p->max_depth; ++ph) {
+                ha.sample = smp; ha.phase = ph;
+                launch_lds(spira::k_hybrid<T>, dim3(hblocks), dim3(spira::kBlock), lds, st, ha);
+            }
+        if (int rc = lds_optin_failed()) return rc;
+        launches += 1 + (uint64_t)p->spp * (p->max_depth + 1);
     } else if (sem == SPIRA_SEM_METAL && metal_wavefront) {
         // the .metal estimator in wavefront form: every wave owns a block of pixels and walks sample after sample on it
         spira::MetalArgs<T> ma{};
@@ -994,7 +1023,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                                1u, (uint32_t)SPIRA_POST_NONE, d_hdr, (T *)nullptr);
         else
             hipLaunchKernelGGL((spira::k_finalize<T>), dim3(fblocks), dim3(spira::kBlock), 0, st, (const P4 *)c.accum.p, (uint32_t)tile_pixels,
-                               p->spp, p->flags & SPIRA_POST_MASK, d_hdr, d_img);
+                               p->spp, sem == SPIRA_SEM_HYBRID ? (uint32_t)SPIRA_POST_NONE : (p->flags & SPIRA_POST_MASK), d_hdr, d_img);      // (HYBRID: the sum is already tone-mapped, K7 per sample)
         ++launches;
     }
     if (progressive && rng_states && !out_on_device)
@@ -1047,6 +1076,7 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     if (int rc = validate_params(camera12, p, triangles10 ? p->n_triangles : 0, &rows)) return rc;
     if (!n_paths || !ijs || !prims || !ts || !dirs || !radiance) return fail(SPIRA_E_INVALID, "NULL argument");
     if (p->max_depth < 1) return fail(SPIRA_E_INVALID, "max_depth must be >= 1");
+    if ((p->flags & SPIRA_SEM_MASK) == SPIRA_SEM_HYBRID) return fail(SPIRA_E_UNSUPPORTED, "SPIRA_SEM_HYBRID has no per-path trace (its samples advance image-wide in lock step)");
     for (uint32_t k = 0; k < n_paths; ++k)
         if (ijs[3 * k] < 1 || ijs[3 * k] > p->width || ijs[3 * k + 1] < 1 || ijs[3 * k + 1] > p->height || ijs[3 * k + 2] >= p->spp)
             return fail(SPIRA_E_INVALID, "path (i, j, sample) out of range");
@@ -1513,7 +1543,7 @@ void spira_shutdown(void) {
         (void)hipDeviceSynchronize();
         for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qX[i].release(); }
         c.mesh_list.release(); c.mesh_count.release();
-        c.redo.release(); c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release();
+        c.redo.release(); c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release(); c.hyb_state.release(); c.hyb_mat.release(); c.hyb_flags.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);
         c.ev_pool.clear();
         for (hipEvent_t e : c.ev_mid) (void)hipEventDestroy(e);

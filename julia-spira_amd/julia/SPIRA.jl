@@ -65,6 +65,7 @@ end
 const SPIRA_SEM_A            = 0x00000000   # ray_color of examples/julia-raytracer.jl (the estimator parity is graded on)
 const SPIRA_SEM_CPU          = 0x00000001   # trace_ray of render_with_cpu :1351-1412
 const SPIRA_SEM_METAL        = 0x00000002   # path_trace of src/spira_path_trace_kernel.metal:140-269
+const SPIRA_SEM_HYBRID       = 0x00000003   # the host loop of render_hybrid_gpu :1228-1343 itself, as written (last bounce shaded, tone map per sample)
 const SPIRA_POST_ACES_GAMMA  = 0x00000100   # the display transform of gpu_tone_map_kernel! :1128-1144
 const SPIRA_POST_CLAMP_GAMMA = 0x00000200   # clamp + sqrt of render_with_cpu :1441-1442
 const SPIRA_POST_NONE        = 0x00000300
@@ -78,7 +79,8 @@ function __init__()                    # a stale library (SPIRA_HIP_LIB, an old 
 end
 
 # which of the reference's estimators runs, and the display transform that goes with it (spira_hip/spira.py: SEMANTICS)
-const SEMANTICS = Dict(:A => (SPIRA_SEM_A, SPIRA_POST_ACES_GAMMA), :cpu => (SPIRA_SEM_CPU, SPIRA_POST_CLAMP_GAMMA), :metal => (SPIRA_SEM_METAL, SPIRA_POST_ACES_GAMMA))
+const SEMANTICS = Dict(:A => (SPIRA_SEM_A, SPIRA_POST_ACES_GAMMA), :cpu => (SPIRA_SEM_CPU, SPIRA_POST_CLAMP_GAMMA), :metal => (SPIRA_SEM_METAL, SPIRA_POST_ACES_GAMMA),
+                       :hybrid => (SPIRA_SEM_HYBRID, SPIRA_POST_NONE))
 semantics_flags(semantics::Symbol, flags) = flags === nothing ? (SEMANTICS[semantics][1] | SEMANTICS[semantics][2]) : Int(flags)
 
 device_count() = Int(ccall((:spira_device_count, libspira), Cint, ()))

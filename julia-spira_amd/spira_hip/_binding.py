@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("SPIRA_HIP_LIB", os.path.join(CSRC, "libspira_hip.so")
 ABI_VERSION = 3      # SPIRA_ABI_VERSION of the include/spira_hip.h this binding was written against (struct layouts, flag values)
 
 # ---- flags (include/spira_hip.h) ----
-SEM_A, SEM_CPU, SEM_METAL = 0x0, 0x1, 0x2
+SEM_A, SEM_CPU, SEM_METAL, SEM_HYBRID = 0x0, 0x1, 0x2, 0x3
 KERNEL_DEFAULT, KERNEL_MEGA, KERNEL_BOUNCE, KERNEL_WAVEFRONT = 0x00, 0x10, 0x20, 0x30
 POST_ACES, POST_ACES_GAMMA, POST_CLAMP_GAMMA, POST_NONE = 0x000, 0x100, 0x200, 0x300
 ROWS_BOTTOM_UP = 0x1000

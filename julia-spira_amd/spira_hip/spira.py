@@ -121,6 +121,7 @@ SEMANTICS = {
     "A": (B.SEM_A, B.POST_ACES_GAMMA),        # ray_color of examples/julia-raytracer.jl, K7 display transform (:1128-1144)
     "cpu": (B.SEM_CPU, B.POST_CLAMP_GAMMA),   # trace_ray of render_with_cpu (:1346-1450): what render() runs on an AMD box today
     "metal": (B.SEM_METAL, B.POST_ACES_GAMMA),  # path_trace of src/spira_path_trace_kernel.metal:140-269
+    "hybrid": (B.SEM_HYBRID, B.POST_NONE),    # the host loop of render_hybrid_gpu itself (:1274-1341) AS WRITTEN: last bounce only, tone map per sample
 }
 
 
@@ -130,8 +131,9 @@ def render_hybrid_gpu(width, height, scene, camera, samples_per_pixel=16, max_de
 
     Returns an (H, W, 3) Float32 image, row 0 = image top (finalize_image_from_gpu_buffer :1157-1190),
     after a display transform.  `seed` is new: the reference never seeds.  `semantics` picks which of the
-    reference's estimators runs (the host loop of :1274-1341 itself shades only the last bounce — a bug that is
-    not reproduced): "A" (default, the parity oracle), "cpu", "metal".
+    reference's estimators runs: "A" (default, the parity oracle), "cpu", "metal", or "hybrid" — the host loop of :1274-1341
+    itself, as written (it shades only the last bounce, tone-maps every sample and ends a sample when no ray of the image
+    hits anything: what the reference shows on a Metal / CUDA machine; `post` is ignored for it).
     """
     sphere_data, material_data = prepare_scene_data(scene)
     sem, default_post = SEMANTICS[semantics]

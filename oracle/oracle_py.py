@@ -126,6 +126,23 @@ def render_variant(spheres5, materials8, camera12, params, prec="f32", n_threads
     return hdr, img, seg.value
 
 
+def render_hybrid(spheres5, materials8, camera12, params, prec="f32", n_threads=0):
+    """SPIRA_SEM_HYBRID: render_hybrid_gpu of src/spira-metal-optimized.jl:1228-1343 as written (whole images only).  Returns (image, segments);
+    the image is the reference's: the mean of per-sample tone-mapped colours, rows in the order the flags ask for."""
+    npdt, cdt, suf = _dt(prec)
+    s, sp = _arr(spheres5, npdt)
+    m, mp = _arr(materials8, npdt)
+    c, cp = _arr(camera12, npdt)
+    hdr = np.empty((3, params.height, params.width), dtype=npdt)
+    seg = C.c_uint64(0)
+    fn = getattr(lib(), "oracle_render_hybrid" + suf)
+    fn.restype = C.c_int
+    rc = fn(sp, mp, cp, C.byref(params), hdr.ctypes.data_as(C.c_void_p), None, C.c_int(n_threads), C.byref(seg))
+    if rc != 0:
+        raise RuntimeError("oracle_render_hybrid%s failed: %d" % (suf, rc))
+    return hdr, seg.value
+
+
 def trace_path_variant(spheres5, materials8, camera12, params, i, j, sample, prec="f32"):
     npdt, cdt, suf = _dt(prec)
     s, sp = _arr(spheres5, npdt)

@@ -29,6 +29,10 @@
 #include "../include/spira_hip.h" /* plain-data spira_params + flag values only */
 #include "../include/spira_spd.h" /* the SPD table of the spectral extension: data shared with the product */
 
+/* xorshift32 of src/spira-metal-optimized.jl:412-417 and its conversion :420-426 (defined below; used by the SPIRA_SEM_HYBRID restatement) */
+uint32_t oracle_xorshift32(uint32_t s);
+float oracle_xorshift_uniform(uint32_t s);
+
 #define ORACLE_MAX_TRIES 64u
 
 /* lowbias32 integer hash (Chris Wellons, public domain) — DESIGN.md "RNG" */

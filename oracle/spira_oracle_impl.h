@@ -732,6 +732,179 @@ int SUF(oracle_trace_path_variant)(const REAL *spheres5, const REAL *materials8,
     return (int)segs;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * SPIRA_SEM_HYBRID — the estimator of render_hybrid_gpu, src/spira-metal-optimized.jl:1228-1343, AS WRITTEN (what `render()` executes on a
+ * machine with a Metal / CUDA backend).  The whole image advances in lock step, one sample after the other, one depth after the other:
+ *   K3  gpu_generate_initial_sample_rays_kernel!  :610-697   per-pixel xorshift32 state (:412-426), jitter of +-0.25 pixel
+ *   K4  gpu_ray_sphere_intersection               :700-799   half-b test, t = t1 > 0.001 ? t1 : t2, strict t < closest: the EARLIER sphere keeps a tie
+ *   --  `if sum(hit_results[:, 1]) == 0 break`    :1303      no ray of the IMAGE hit anything: the sample ends (and adds nothing if depth < max_depth)
+ *   K5  gpu_scatter_kernel!                       :862-989   a ray that missed carries on from (0, 0, 0) in its old direction; a mirror reflection is not normalised
+ *   --  `contribution .*= 0.5f0`                  :1328      for every ray, hit or not
+ *   K6  gpu_shade_kernel!                         :1071-1105 only at depth == max_depth: albedo * contribution + emission of the LAST hit, or the sky along the NEW direction
+ *   K7  gpu_tone_map_kernel!                      :1128-1144 ACES + sqrt, per sample
+ *   K8  average_image_kernel! + the row flip      :1055-1068, :1157-1190
+ * The reference documents none of this as intended (:1331-1338 call it a "simple model"); it is restated, not repaired.  Its per-pixel states are
+ * rand(UInt32) (:1258): here derived from the seed.  The unbounded rejection loop of K5 is bounded at 64 tries like everywhere else.
+ * Whole images only (the lock step needs every pixel): params->rows must be 0.  out_hdr = out_img = the reference's image (already tone-mapped per sample). */
+static inline REAL SUF(xs_uniform)(uint32_t s) { return (REAL)oracle_xorshift_uniform(s); }      /* Float32(state / typemax(UInt32)), :420-426 */
+static inline REAL SUF(aces_sqrt)(REAL x) {                                                        /* :1133-1143 */
+    const REAL a = (REAL)2.51f, b = (REAL)0.03f, c = (REAL)2.43f, d = (REAL)0.59f, e = (REAL)0.14f;
+    REAL r = (x * (a * x + b)) / (x * (c * x + d) + e);
+    r = r < (REAL)0 ? (REAL)0 : (r > (REAL)1 ? (REAL)1 : r);
+    return SQRT(r);
+}
+int SUF(oracle_render_hybrid)(const REAL *spheres5, const REAL *materials8, const REAL *camera12, const spira_params *p,
+                              REAL *out_hdr, REAL *out_img, int n_threads, uint64_t *segments_out) {
+    if (!materials8 || !camera12 || !p || (!spheres5 && p->n_spheres)) return -1;
+    if ((p->flags & SPIRA_SEM_MASK) != SPIRA_SEM_HYBRID) return -5;
+    if (p->rows != 0) return -5;
+    World w; SUF(world_init)(&w, spheres5, materials8, NULL, camera12, p);
+    const uint32_t W = p->width, H = p->height;
+    const size_t P = (size_t)W * H;
+    typedef struct { V3 o, d, pt, n; uint32_t mat, rng; V3 sum; } Px;
+    Px *px = (Px *)malloc(P * sizeof(Px));
+    if (!px) return -3;
+    uint64_t segments = 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    for (size_t k = 0; k < P; ++k) { px[k].rng = SUF(metal_state0)(&w, (uint32_t)k); px[k].sum = SUF(v3)(0, 0, 0); }      /* rand(UInt32, width*height), :1258 */
+    for (uint32_t sample = 1; sample <= p->spp; ++sample) {                                          /* :1275 */
+        /* ---- K3 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+        for (size_t k = 0; k < P; ++k) {
+            uint32_t st = oracle_xorshift32(px[k].rng + sample);                                     /* :632 */
+            st = oracle_xorshift32(st); const REAL rand1 = SUF(xs_uniform)(st);                      /* :635-636 */
+            st = oracle_xorshift32(st); const REAL rand2 = SUF(xs_uniform)(st);                      /* :637-638 */
+            px[k].rng = st;                                                                          /* :641 */
+            const uint32_t col = (uint32_t)(k % W), row = (uint32_t)(k / W);                         /* :651-652 */
+            const REAL u_center = (REAL)col / (REAL)(W - 1), v_center = (REAL)row / (REAL)(H - 1);   /* :656-657 */
+            const REAL pw = (REAL)1.0 / (REAL)(W - 1), ph = (REAL)1.0 / (REAL)(H - 1);               /* :669-670 */
+            const REAL u = u_center + (rand1 - (REAL)0.5) * (REAL)0.5 * pw;                          /* :672 (jitter_scale_factor = 0.5f0, :1286) */
+            const REAL v = v_center + (rand2 - (REAL)0.5) * (REAL)0.5 * ph;                          /* :673 */
+            const REAL dx = w.cam_llc.x + u * w.cam_hor.x + v * w.cam_ver.x - w.cam_origin.x;        /* :676 */
+            const REAL dy = w.cam_llc.y + u * w.cam_hor.y + v * w.cam_ver.y - w.cam_origin.y;
+            const REAL dz = w.cam_llc.z + u * w.cam_hor.z + v * w.cam_ver.z - w.cam_origin.z;
+            const REAL len_sq = dx * dx + dy * dy + dz * dz;                                         /* :681 */
+            const REAL inv_len = len_sq > (REAL)0 ? SQRT((REAL)1.0 / len_sq) : (REAL)0;              /* :682 */
+            px[k].o = w.cam_origin;
+            px[k].d = SUF(v3)(dx * inv_len, dy * inv_len, dz * inv_len);                             /* :689-691 */
+        }
+        REAL contribution = (REAL)1.0;                                                               /* Metal.ones, :1294 */
+        for (uint32_t depth = 1; depth <= p->max_depth; ++depth) {                                   /* :1297 */
+            /* ---- K4 */
+            int any_hit = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(| : any_hit)
+#endif
+            for (size_t k = 0; k < P; ++k) {
+                const V3 o = px[k].o, d = px[k].d;
+                uint32_t mat = 0; REAL best = (REAL)1e20f;                                           /* :713-715 */
+                V3 pt = SUF(v3)(0, 0, 0), nn = SUF(v3)(0, 0, 0);                                     /* :718-719 */
+                for (uint32_t s = 0; s < w.n_spheres; ++s) {                                         /* :724 */
+                    const REAL *s5 = w.spheres5 + 5 * (size_t)s;
+                    const REAL ocx = o.x - s5[0], ocy = o.y - s5[1], ocz = o.z - s5[2];              /* :735-737 */
+                    const REAL a = d.x * d.x + d.y * d.y + d.z * d.z;                                /* :740 */
+                    const REAL half_b = ocx * d.x + ocy * d.y + ocz * d.z;                           /* :741-743 */
+                    const REAL c = ocx * ocx + ocy * ocy + ocz * ocz - s5[3] * s5[3];                /* :744 */
+                    const REAL disc = half_b * half_b - a * c;                                       /* :747 */
+                    if (!(disc > (REAL)0)) continue;                                                 /* :750 */
+                    const REAL sq = SQRT(disc);                                                      /* :759 */
+                    const REAL t1 = (-half_b - sq) / a, t2 = (-half_b + sq) / a;                     /* :760-761 */
+                    const REAL t = t1 > (REAL)0.001f ? t1 : t2;                                      /* :764 */
+                    if (t <= (REAL)0.001f || t >= best) continue;                                    /* :767 */
+                    best = t; mat = (uint32_t)s5[4];                                                 /* :772-774 */
+                    pt = SUF(v3)(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);                       /* :777-779 */
+                    const REAL nx = pt.x - s5[0], ny = pt.y - s5[1], nz = pt.z - s5[2];              /* :782-784 */
+                    const REAL il = (REAL)1.0 / SQRT(nx * nx + ny * ny + nz * nz);                   /* :787 */
+                    nn = SUF(v3)(nx * il, ny * il, nz * il);                                         /* :788-790 */
+                }
+                px[k].mat = mat; px[k].pt = pt; px[k].n = nn;
+                if (mat) any_hit = 1;
+            }
+            segments += P;
+            if (!any_hit) break;                                                                     /* :1303-1310 */
+            /* ---- K5 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+            for (size_t k = 0; k < P; ++k) {
+                Px *q = &px[k];
+                q->o = q->pt;                                                                        /* :883-885: (0, 0, 0) for a ray that missed */
+                if (!q->mat) continue;                                                               /* :888 */
+                const REAL *m = w.materials8 + 8 * (size_t)(q->mat - 1);                             /* :890-891 */
+                const REAL metallic = m[6], roughness = m[7];
+                const REAL nx = q->n.x, ny = q->n.y, nz = q->n.z, dx = q->d.x, dy = q->d.y, dz = q->d.z;
+                const REAL dot_prod = dx * nx + dy * ny + dz * nz;                                   /* :904 */
+                if (metallic > (REAL)0) {                                                            /* :907 */
+                    REAL rx = dx - (REAL)2.0 * dot_prod * nx, ry = dy - (REAL)2.0 * dot_prod * ny, rz = dz - (REAL)2.0 * dot_prod * nz;   /* :908-910 */
+                    if (roughness > (REAL)0) {                                                       /* :912 */
+                        uint32_t st = q->rng;
+                        st = oracle_xorshift32(st); REAL r1 = SUF(xs_uniform)(st) - (REAL)0.5;       /* :914-921 */
+                        st = oracle_xorshift32(st); REAL r2 = SUF(xs_uniform)(st) - (REAL)0.5;
+                        st = oracle_xorshift32(st); REAL r3 = SUF(xs_uniform)(st) - (REAL)0.5;
+                        q->rng = st;
+                        const REAL nl = SQRT(r1 * r1 + r2 * r2 + r3 * r3);                           /* :927 */
+                        if (nl > (REAL)1e-5f) { const REAL il = (REAL)1.0 / nl; r1 *= il; r2 *= il; r3 *= il; }   /* :928-933 */
+                        rx += roughness * r1; ry += roughness * r2; rz += roughness * r3;            /* :935-937 */
+                        const REAL il = (REAL)1.0 / SQRT(rx * rx + ry * ry + rz * rz);               /* :939 */
+                        rx *= il; ry *= il; rz *= il;
+                    }
+                    q->d = SUF(v3)(rx, ry, rz);                                                      /* :944-946 */
+                } else {                                                                             /* :947 */
+                    uint32_t st = q->rng;
+                    REAL lx = 0, ly = 0, lz = 0;
+                    for (int tries = 0; tries < 64; ++tries) {                                       /* while true, :950-963 */
+                        st = oracle_xorshift32(st); const REAL r1 = SUF(xs_uniform)(st);
+                        st = oracle_xorshift32(st); const REAL r2 = SUF(xs_uniform)(st);
+                        st = oracle_xorshift32(st); const REAL r3 = SUF(xs_uniform)(st);
+                        lx = r1 * (REAL)2.0 - (REAL)1.0; ly = r2 * (REAL)2.0 - (REAL)1.0; lz = r3 * (REAL)2.0 - (REAL)1.0;
+                        if (lx * lx + ly * ly + lz * lz <= (REAL)1.0) break;
+                        if (tries == 63) { lx = ly = lz = 0; }
+                    }
+                    q->rng = st;                                                                     /* :964 */
+                    const REAL ddx = nx + lx, ddy = ny + ly, ddz = nz + lz;                          /* :966-968 */
+                    const REAL ls = ddx * ddx + ddy * ddy + ddz * ddz;                               /* :970 */
+                    if (ls < (REAL)1e-5f) q->d = SUF(v3)(nx, ny, nz);                                /* :971-974 */
+                    else { const REAL il = (REAL)1.0 / SQRT(ls); q->d = SUF(v3)(ddx * il, ddy * il, ddz * il); }   /* :976-979 */
+                }
+            }
+            contribution *= (REAL)0.5;                                                               /* :1328 */
+            if (depth == p->max_depth) {                                                             /* :1331 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+                for (size_t k = 0; k < P; ++k) {
+                    REAL cr, cg, cb;
+                    if (px[k].mat) {                                                                 /* K6, :1084-1096 */
+                        const REAL *m = w.materials8 + 8 * (size_t)(px[k].mat - 1);
+                        cr = m[0] * contribution + m[3]; cg = m[1] * contribution + m[4]; cb = m[2] * contribution + m[5];
+                    } else {                                                                         /* :1097-1102 */
+                        const REAL t = (REAL)0.5 * (px[k].d.y + (REAL)1.0);
+                        cr = ((REAL)1.0 - t) + t * (REAL)0.5; cg = ((REAL)1.0 - t) + t * (REAL)0.7f; cb = ((REAL)1.0 - t) + t * (REAL)1.0;
+                    }
+                    px[k].sum.x += SUF(aces_sqrt)(cr); px[k].sum.y += SUF(aces_sqrt)(cg); px[k].sum.z += SUF(aces_sqrt)(cb);   /* K7 + :1334 */
+                }
+            }
+        }
+    }
+    for (uint32_t y = 0; y < H; ++y) {                                                               /* K8 and the row flip, :1055-1068, :1177-1188 */
+        const uint32_t row = (p->flags & SPIRA_ROWS_BOTTOM_UP) ? y : H - 1 - y;
+        for (uint32_t x = 0; x < W; ++x) {
+            const Px *q = &px[(size_t)row * W + x];
+            const REAL r = q->sum.x / (REAL)p->spp, g = q->sum.y / (REAL)p->spp, b = q->sum.z / (REAL)p->spp;
+            const size_t o = (size_t)y * W + x;
+            if (out_hdr) { out_hdr[o] = r; out_hdr[P + o] = g; out_hdr[2 * P + o] = b; }
+            if (out_img) { out_img[o] = r; out_img[P + o] = g; out_img[2 * P + o] = b; }
+        }
+    }
+    free(px);
+    if (segments_out) *segments_out = segments;
+    return 0;
+}
+
 void SUF(oracle_sincos_turn)(REAL r, REAL *sc2) { SUF(sincos_turn)(r, &sc2[0], &sc2[1]); }
 
 #undef V3

@@ -321,7 +321,7 @@ def test_julia_export_lists_cover_the_reference_and_the_python_twins():
     assert twin <= ex, twin - ex
     for kw in ("semantics::Symbol=:A", "flags=nothing"):      # the estimator can be chosen from Julia too (spira.py: semantics=)
         assert kw in src[src.index("function render(scene::Scene"):], kw
-    assert set(re.findall(r":(A|cpu|metal) =>", src)) == set(spira.SEMANTICS) == {"A", "cpu", "metal"}
+    assert set(re.findall(r":(A|cpu|metal|hybrid) =>", src)) == set(spira.SEMANTICS) == {"A", "cpu", "metal", "hybrid"}
     ex, src = _julia_exports("Raytracer.jl")
     # the functions of /root/reference/examples/julia-raytracer.jl that tests/bunny-test.jl:37-60 and the script's own main() call
     assert {"Vec3", "Ray", "Material", "Sphere", "Triangle", "Mesh", "HittableList", "BoundingVolumeHierarchy", "Camera", "render", "to_acescg", "save_exr",

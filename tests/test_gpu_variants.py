@@ -130,3 +130,55 @@ def test_metal_wavefront_progressive_and_full_size(gpu):
     seg = gpu.counters()["segments"]
     b, _ = gpu.render(sp, ma, None, cam, gpu.make_params(W, H, 64, 8, 5, 5, 0, flags=gpu.SEM_METAL | gpu.KERNEL_MEGA | gpu.POST_NONE, seed=7), "f32")
     assert np.array_equal(a, b) and gpu.counters()["segments"] == seg and np.isfinite(a).all()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_hybrid_estimator_equals_the_oracle_bitwise(gpu, oracle, prec):
+    """SPIRA_SEM_HYBRID = render_hybrid_gpu as written (src/spira-metal-optimized.jl:1228-1343): per-pixel xorshift32 jitter, image-wide lock step,
+    last bounce shaded, tone map per sample.  Same statements in the same order in oracle and kernel (k_hybrid), no reduction whose order could differ:
+    the images are the same BITS, and so are the intersection counts; both row orders; a scene nobody hits stays black (the image-wide break)."""
+    sp, ma, cam = _scene()
+    for (W, H, spp, depth, extra) in ((97, 55, 5, 4, 0), (64, 36, 3, 7, 0x1000), (33, 20, 2, 1, 0)):
+        pg = gpu.make_params(W, H, spp, depth, 5, 5, 0, flags=0x3 | extra, seed=21)
+        hdr, img = gpu.render(sp, ma, None, cam, pg, prec, want_hdr=True, want_img=True)
+        want, seg = oracle.render_hybrid(sp, ma, cam, oracle.make_params(W, H, spp, depth, 5, 5, 0, flags=0x3 | extra, seed=21), prec)
+        assert np.array_equal(hdr, want) and np.array_equal(img, want), (W, H, float(np.abs(hdr - want).max()))
+        assert gpu.counters()["segments"] == seg == W * H * spp * depth
+    empty, _ = gpu.render(None, ma, None, cam, gpu.make_params(32, 18, 2, 3, 0, 5, 0, flags=0x3, seed=1), prec)
+    assert float(np.abs(empty).max()) == 0.0 and gpu.counters()["segments"] == 32 * 18 * 2
+
+
+def test_hybrid_estimator_limits_and_mirror(gpu, oracle):
+    sp, ma, cam = _scene()
+    with pytest.raises(gpu.SpiraError):          # whole images only: the lock step needs every pixel
+        gpu.render(sp, ma, None, cam, gpu.make_params(32, 18, 2, 3, 5, 5, 0, flags=0x3, seed=1, rows=8), "f32")
+    with pytest.raises(gpu.SpiraError):          # spheres only, like its source
+        tri = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0, 1]], dtype=np.float64)
+        gpu.render(sp, ma, tri, cam, gpu.make_params(32, 18, 2, 3, 5, 5, 1, flags=0x3, seed=1), "f32")
+    with pytest.raises(gpu.SpiraError):          # no accumulate entry
+        gpu.accumulate(sp, ma, None, cam, gpu.make_params(32, 18, 2, 3, 5, 5, 0, flags=0x3, seed=1), 0, np.zeros((3, 18, 32), np.float32), prec="f32")
+    # the package surface: render_hybrid_gpu(...; semantics = "hybrid") of the Python mirror (SPIRA.jl: semantics = :hybrid)
+    from spira_hip import spira as S
+    scene = S.create_scene()
+    camera = S.Camera(S.Point3(0, 1, 3), S.Point3(0, 0, 0), S.Vec3(0, 1, 0), 40.0, 16 / 9)
+    img = S.render_hybrid_gpu(48, 27, scene, camera, samples_per_pixel=3, max_depth=4, seed=6, semantics="hybrid")
+    sd, md = S.prepare_scene_data(scene)
+    want, _ = oracle.render_hybrid(sd.reshape(-1, 5), md.reshape(-1, 8), camera.flat(), oracle.make_params(48, 27, 3, 4, 5, 5, 0, flags=0x3, seed=6), "f32")
+    assert img.shape == (27, 48, 3) and np.array_equal(np.moveaxis(img, -1, 0), want)
+
+
+def test_hybrid_estimator_fuzz(gpu, oracle):
+    """Random sphere scenes (metals, rough metals, diffuse, emitters), image sizes, spp, depths, precisions, row orders: SPIRA_SEM_HYBRID == its oracle, bit for bit."""
+    from test_gpu_parity import random_scene
+    rng = np.random.default_rng(20261006)
+    for it in range(24):
+        s = random_scene(rng, int(rng.integers(1, 12)), 0)
+        ns, nm = len(s["spheres5"]), len(s["materials8"])
+        W, H, spp, depth = int(rng.integers(2, 80)), int(rng.integers(2, 50)), int(rng.integers(1, 6)), int(rng.integers(0, 9))
+        prec = "f32" if rng.random() < 0.5 else "f64"
+        fl = 0x3 | (0x1000 if rng.random() < 0.3 else 0) | int(rng.choice([0x00, 0x10, 0x30]))          # (the organisation flags are ignored)
+        seed = int(rng.integers(0, 2 ** 40))
+        hdr, _ = gpu.render(s["spheres5"], s["materials8"], None, s["camera12"], gpu.make_params(W, H, spp, depth, ns, nm, 0, flags=fl, seed=seed), prec)
+        want, seg = oracle.render_hybrid(s["spheres5"], s["materials8"], s["camera12"], oracle.make_params(W, H, spp, depth, ns, nm, 0, flags=fl, seed=seed), prec)
+        assert np.array_equal(hdr, want), (it, W, H, spp, depth, prec, float(np.abs(hdr - want).max()))
+        assert gpu.counters()["segments"] == seg, it
