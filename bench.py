@@ -59,7 +59,9 @@ def kernel_source_hash():
     profiles/traffic_*.json carry the id of the library they were measured on (profiles/summarize.py), and PMC figures of another build are never
     attached to a bench line."""
     import subprocess
-    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "julia-spira_amd", "csrc"), "build_id"], check=True, capture_output=True, text=True).stdout
+    # (a clean environment for the child: under rocprofv3 the profiler's preloaded library would initialise the GPU in `make` and in everything make starts)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER", "HSA_TOOLS"))}
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "julia-spira_amd", "csrc"), "build_id"], check=True, capture_output=True, text=True, env=env).stdout
     return out.strip().splitlines()[-1].strip()
 
 

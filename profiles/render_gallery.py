@@ -25,7 +25,11 @@ def glass_s2():
 
 jobs = [("s2_ext_dielectric", glass_s2(), B.EXT_DIELECTRIC, 10), ("s2_ext_dielectric_spectral", glass_s2(), B.EXT_DIELECTRIC | B.EXT_SPECTRAL, 10),
         ("s1_semA", scenes.scene_s1(), 0, 8), ("s1_semCPU", scenes.scene_s1(), 1, 8), ("s1_semMETAL", scenes.scene_s1(), 2, 8),
-        ("s2_semA", scenes.scene_s2(), 0, 8), ("s3_closed_box", scenes.scene_s3(), 0, 8), ("s4_mesh_bvh", scenes.scene_s4(6), 0, 12)]
+        ("s2_semA", scenes.scene_s2(), 0, 8), ("s3_closed_box", scenes.scene_s3(), 0, 8), ("s4_mesh_bvh", scenes.scene_s4(6), 0, 12),
+        ("s5_mesh_stress", scenes.scene_s5(6), 0, 12),                 # round 4: the mesh stress scene (the mesh fills 70 % of the frame)
+        ("s1_semHYBRID", scenes.scene_s1(), 3, 4)]                     # round 4: render_hybrid_gpu's own estimator as written (last bounce only, tone map per sample)
+if len(sys.argv) > 1:
+    jobs = [j for j in jobs if j[0] in sys.argv[1:]]
 for name, s, sem, depth in jobs:
     ns, nm = len(s["spheres5"]), len(s["materials8"])
     nt = 0 if s["triangles10"] is None else len(s["triangles10"])
