@@ -1432,6 +1432,7 @@ template <class T> struct PathArgs {
     RenderConst<T> rc;
     RayQueue<T> q[2];                // stage k writes q[k & 1] and (k >= 1) reads q[(k + 1) & 1]
     uint32_t *qref[2];               // Float32 only: the hit reference of each queued packet (Float64 packs it beside q)
+    uint2 *qkey[2];                  // sphere scenes without extensions: the path's half-made RNG key beside each packet (k_path, kCarry)
     Pack3<T> *L;                     // per-path radiance of the pass batch (slot-major)
     uint32_t *blk_stats;             // [NW][4] segments, radiance RMWs, radiance stores, packets enqueued
     uint32_t cap;                    // region size in packets (a multiple of R*64)
@@ -1474,6 +1475,9 @@ __device__ unsigned long long g_mesh_dbg[32];        // [16..31]: the same for t
 
 // MODE (mesh scenes, PathArgs::mesh_mode): 0 = one launch with the traversal sessions inside, 1 = first of two launches (parks, never walks: the
 // session code is not compiled in — it cost the first launch 9 % through register allocation alone), 2 = second launch (no camera rays).
+#ifndef SPIRA_CARRY_KEY
+#define SPIRA_CARRY_KEY 1        // paths carry their half-made RNG key through the hit queue (k_path, kCarry); 0: derived from the path index at every scatter
+#endif
 #ifndef SPIRA_WAVES_B_F32
 #define SPIRA_WAVES_B_F32 4      // the second launch of a mesh pass runs 16 fat waves per CU = 4 per SIMD whatever the kernel allows: 128 registers instead of 96
 #endif                           // (35 spilled VGPRs less) is config 5 Float32 4.33 -> 4.11 ms.  (The parking launch with 4 / 3 waves per SIMD: +2 % / +4 % frame time.)
@@ -1489,6 +1493,12 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
     extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
     constexpr uint32_t WPB = kBlock / 64, SUB = 64 * R;
     constexpr bool kRefArray = sizeof(T) == 4;
+    // The RNG key of a scatter is mix32(mix32(sA + pixel) ^ sb), mix32(mix32(sB ^ pixel) + sb) with sb = sample << 8 | bounce (rng_key).  With
+    // bounce < 256 the `| bounce` is an XOR / an addition of its own, so a path can carry ka = mix32(sA + pixel) ^ (sample << 8) and
+    // kb = mix32(sB ^ pixel) + (sample << 8) — two words made once from the camera ray's pixel and sample — and a scatter derives its key with two mixes
+    // instead of two divisions (path index -> pixel, sample) and four.  Same bits; the mesh and extension instantiations keep the derivation from q
+    // (their parked entries have no room for the words, and the extensions need pixel and sample anyway).
+    constexpr bool kCarry = SPIRA_CARRY_KEY && !BVH && !EXT;
     constexpr uint32_t kStageShift = 25, kRefMask = (1u << kStageShift) - 1u;      // a hit reference needs < 2^25; the packet's stage rides above it
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t NW = gridDim.x * WPB, wid = blockIdx.x * WPB + wave;
@@ -1572,6 +1582,8 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
         const RayQueue<T> qin = a.q[(round + 1) & 1], qout = a.q[round & 1];
         const uint32_t *rin = a.qref[(round + 1) & 1];
         uint32_t *rout = a.qref[round & 1];
+        const uint2 *kin = a.qkey[(round + 1) & 1];
+        uint2 *kout = a.qkey[round & 1];
         const uint32_t limit = first ? a.n_first : n_in;
         const uint32_t n_sub = first ? n_sub_first : (n_in + SUB - 1) / SUB;
         uint32_t fill = 0;
@@ -1580,12 +1592,13 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
             Pending<T> pend[R];                           // between trips pend[r].v holds the direction the hit was reached along
             ExtState<T> ex[R];                            // EXT instantiations only (dead otherwise)
             uint32_t q[R], ent[R], stg[R], ref[R];
+            uint32_t ka[R], kb[R];                        // kCarry: the path's half-made RNG key
             bool valid[R];
             // ---------------- the sub-chunk's rays: camera rays + their closest hit (round 0) or queued hits
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const uint32_t idx = sub * SUB + r * 64 + lane;
-                valid[r] = false; stg[r] = round; ref[r] = 0; q[r] = 0;
+                valid[r] = false; stg[r] = round; ref[r] = 0; q[r] = 0; ka[r] = 0; kb[r] = 0;
                 pend[r].kind = kDead; pend[r].rough = 0; pend[r].v = mk<T>(0, 0, 0);
                 o[r] = mk<T>(0, 0, 0); beta[r] = mk<T>(1, 1, 1);
                 bool parked = false; T park_t = 0; int park_prim = -1;
@@ -1595,6 +1608,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                         Vec<T> d;
                         q[r] = idx;
                         path_of<T>(rc, idx, a.pass, pi, pj, pixel, sample);
+                        if (kCarry) { ka[r] = mix32(rc.sA + pixel) ^ (sample << 8); kb[r] = mix32(rc.sB ^ pixel) + (sample << 8); }
                         camera_ray_lds<T>(rc, cam_lds, pix_div, pi, pj, pixel, sample, o[r], d, pol);
                         if (EXT) { ex[r].flags = rc.flags; if (rc.flags & kExtSpectral) beta[r] = ext_wavelength<T>(sc, rc.sA, rc.sB, pixel, sample, ex[r]); }
                         T t; uint32_t slot = 0;
@@ -1626,6 +1640,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                         uint32_t w;
                         if constexpr (kRefArray) w = rin[region + idx]; else w = unpack_ref(C.y);
                         if (mixed) { stg[r] = w >> kStageShift; ref[r] = w & kRefMask; } else ref[r] = w;
+                        if (kCarry) { const uint2 k = kin[region + idx]; ka[r] = k.x; kb[r] = k.y; }
                         valid[r] = true;
                     }
                 }
@@ -1674,8 +1689,12 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                         }
                         want = (pend[r].kind == kDiffuse || pend[r].kind == kSpecRough);
                         if (want || (EXT && pend[r].kind == kDielectric)) {
-                            if (!EXT) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
-                            key = rng_key(rc.sA, rc.sB, pixel, sample, stg[r]);
+                            if (kCarry && mixed) {                // (max_depth <= 128: the bounce fits the low byte)
+                                key.hA = mix32(ka[r] ^ stg[r]); key.hB = mix32(kb[r] + stg[r]); key.hBr = (key.hB << 16) | (key.hB >> 16);
+                            } else {
+                                if (!EXT) path_of<T>(rc, qi, a.pass, pi, pj, pixel, sample);
+                                key = rng_key(rc.sA, rc.sB, pixel, sample, stg[r]);
+                            }
                             if (EXT && pend[r].kind == kDielectric) dielectric_resolve<T>(pend[r], d, key);     // -> kMirror
                         }
                     }
@@ -1782,6 +1801,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                         C.x = beta[r].z; C.y = pack_qref(q[r], w, (T)0);
                         qout.A[dst] = A; qout.B[dst] = B; qout.C[dst] = C;
                         if constexpr (kRefArray) rout[dst] = w;
+                        if constexpr (kCarry) kout[dst] = make_uint2(ka[r], kb[r]);
                     }
                     fill += (uint32_t)__popcll(m);
                 }

@@ -101,7 +101,7 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    DevBuf qA[2], qB[2], qC[2], qR[2], qX[2], mesh_list, mesh_count, redo, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
+    DevBuf qA[2], qB[2], qC[2], qR[2], qK[2], qX[2], mesh_list, mesh_count, redo, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
     DevBuf hyb_state, hyb_mat, hyb_flags;          // SPIRA_SEM_HYBRID: per-pixel ray state between its launches
     DevBuf spd32, spd64;                          // SPIRA_EXT_SPECTRAL: the SPD table, uploaded once per precision
     DevBuf multi_tile, multi_stack, multi_full;   // spira_render_multi_*: this device's tile; device 0: the gathered tiles, the frame
@@ -621,6 +621,7 @@ int ensure_path_plan(Ctx &c, const PathPlan &pl) {
             if (int rc = c.qB[i].ensure(pl.packets * sizeof(P4))) return rc;
             if (int rc = c.qC[i].ensure(pl.packets * sizeof(P2))) return rc;
             if (sizeof(T) == 4) { if (int rc = c.qR[i].ensure(pl.packets * sizeof(uint32_t))) return rc; }
+            if (!pl.mesh) { if (int rc = c.qK[i].ensure(pl.packets * sizeof(uint2))) return rc; }      // carried RNG keys (sphere scenes; the extension launches leave them unused)
         }
     if (pl.mesh) { if (int rc = c.mesh_list.ensure(3 * pl.packets * sizeof(P4))) return rc; }
     if (pl.two_pass) { if (int rc = c.mesh_count.ensure(pl.waves * sizeof(uint32_t))) return rc; }
@@ -642,6 +643,7 @@ int verify_path_args(const Ctx &c, const spira::PathArgs<T> &a, uint32_t first_l
         for (int i = 0; i < 2 && !bad; ++i) {
             if (!covers(c.qA[i], a.q[i].A, n * sizeof(P4)) || !covers(c.qB[i], a.q[i].B, n * sizeof(P4)) || !covers(c.qC[i], a.q[i].C, n * sizeof(P2))) bad = "hit queues";
             else if (sizeof(T) == 4 && !covers(c.qR[i], a.qref[i], n * sizeof(uint32_t))) bad = "hit reference arrays";
+            else if (!mesh && !covers(c.qK[i], a.qkey[i], n * sizeof(uint2))) bad = "carried RNG keys";
         }
     if (!bad && a.mesh_list && !covers(c.mesh_list, a.mesh_list, 3 * n * sizeof(P4))) bad = "mesh lists";
     if (!bad && a.mesh_mode != 0 && (!a.mesh_list || !covers(c.mesh_count, a.mesh_count, nw * sizeof(uint32_t)) || a.resume_k == 0 || a.resume_k > 16 || nw % a.resume_k != 0 || a.resume_nw != nw))
@@ -945,6 +947,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 for (int i = 0; i < 2; ++i) {
                     pa.q[i] = {(P4 *)c.qA[i].p, (P4 *)c.qB[i].p, (P2 *)c.qC[i].p};
                     pa.qref[i] = (uint32_t *)c.qR[i].p;
+                    pa.qkey[i] = (uint2 *)c.qK[i].p;
                 }
                 pa.blk_stats = (uint32_t *)c.blkstats.p;
                 pa.stats = (spira::Stats *)c.stats.p;
@@ -1541,7 +1544,7 @@ void spira_shutdown(void) {
         if (!c.init) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
-        for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qX[i].release(); }
+        for (int i = 0; i < 2; ++i) { c.qA[i].release(); c.qB[i].release(); c.qC[i].release(); c.qR[i].release(); c.qK[i].release(); c.qX[i].release(); }
         c.mesh_list.release(); c.mesh_count.release();
         c.redo.release(); c.L.release(); c.accum.release(); c.counts.release(); c.blkstats.release(); c.stats.release(); c.scene.release(); c.out_tmp.release(); c.trace.release(); c.rng.release(); c.multi_tile.release(); c.multi_stack.release(); c.multi_full.release(); c.spd32.release(); c.spd64.release(); c.hyb_state.release(); c.hyb_mat.release(); c.hyb_flags.release();
         for (hipEvent_t e : c.ev_pool) (void)hipEventDestroy(e);

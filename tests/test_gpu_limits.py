@@ -25,6 +25,20 @@ def test_max_depth_255(gpu, oracle):
     assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg and oseg > 48 * 27 * 2 * 200
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_carried_rng_key_depth_boundary(gpu, oracle, prec):
+    """Paths of a sphere scene carry their half-made RNG key through the hit queue while the bounce fits the key's low byte (max_depth <= 128:
+    k_path, kCarry); deeper renders derive it from the path index at every scatter.  Both sides of the boundary, bit for bit, on a scene that
+    compacts (S1: open) and one that never leaves the registers (S3: closed)."""
+    for mk in (scenes.scene_s1, scenes.scene_s3):
+        s = mk()
+        ns, nm, nt = _counts(s)
+        for depth in (128, 129):
+            hdr, _ = gpu.render(*_args(s), gpu.make_params(40, 24, 2, depth, ns, nm, nt, seed=21), prec)
+            ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(40, 24, 2, depth, ns, nm, nt, seed=21), prec)
+            assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg, (mk.__name__, depth)
+
+
 def test_4k_frame_runs_and_matches_tiles(gpu):
     """3840x2160 (8.3 M pixels): several slots per pass; the top half rendered as a slab equals the full frame's top half."""
     s = scenes.scene_s1()
