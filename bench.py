@@ -446,7 +446,7 @@ def main():
                 hdr_host, _ = B.render(sc[0], sc[1], sc[2], sc[3], params, args.prec)
             e2e = (time.perf_counter() - t1) / 3
             end_to_end = {"ms": round(e2e * 1e3, 3), "value": round(samples_per_step / e2e / 1e6, 3), "unit": "Msamples/s", "d2h_bytes": int(hdr_host.nbytes),
-                          "what": "spira_render_%s with host pointers: scene validation + upload, kernels, the planar frame to pageable host memory (device -> pinned staging in chunks, host threads move them on), synchronous" % args.prec}
+                          "what": "spira_render_%s with host pointers: scene validation + upload, kernels, the planar frame to freshly allocated pageable host memory (rendered as row slabs: a slab goes device -> pinned staging -> host threads -> the caller's pages beside the next slab's kernels), synchronous; the loop also pays the allocator for dropping the previous 50 MB array" % args.prec}
             # the call shape of SPIRA.jl's render(scene, camera, W, H) (src/spira-metal-optimized.jl:1453-1490 returns Matrix{RGB{Float32}}): Float32, the display image
             # only (out_hdr = NULL), ACES + gamma: 24.9 MB to the host
             s32 = [np.ascontiguousarray(a, dtype=np.float32) if a is not None else None for a in sc]

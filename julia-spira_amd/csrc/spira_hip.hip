@@ -8,6 +8,7 @@
 // + 1 resolve kernel, fully asynchronous on one HIP stream, the live-ray counts staying on the
 // device, and a pass carries `slots` samples of every pixel of the tile at once.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <rccl/rccl.h>      // types and prototypes only: librccl is opened at run time (dlopen), never linked
 #include <dlfcn.h>
 
@@ -46,9 +47,12 @@
 #error "SPIRA_TU_MAIN, SPIRA_TU_F32 and SPIRA_TU_F64MESH are three different translation units"
 #endif
 struct spira_scene;
+// A host-output frame rendered as `count` consecutive row slabs (render_host_slabs): slab `index` > 0 continues the call of slab 0 — same scene (already in
+// the context's store), same counters and event brackets (they add up), and the caller holds the context's lock across all of them.
+struct SlabCtl { uint32_t index, count; };
 namespace spira_tu {      // defined in the SPIRA_TU_F32 unit, called from the SPIRA_TU_MAIN one
 int render_impl_f32(const spira_scene *h, const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
-                    float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states);
+                    float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states, const SlabCtl *slab);
 int trace_impl_f32(const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
                    uint32_t n_paths, const uint32_t *ijs, int *prims, float *ts, float *dirs, float *radiance);
 // defined in the SPIRA_TU_F64MESH unit: launch_path<double> of a mesh scene (PathArgs::mesh_mode 0 or 1) and launch_path_resume<double> (mode 2)
@@ -101,6 +105,8 @@ struct Ctx {
     int device = -1;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;        // host-output frames rendered as row slabs: a slab's copies run here, beside the next slab's kernels
+    hipEvent_t ev_slab = nullptr;
     DevBuf qA[2], qB[2], qC[2], qR[2], qK[2], qX[2], mesh_list, mesh_count, redo, L, accum, counts, blkstats, stats, out_tmp, trace, rng;
     DevBuf hyb_state, hyb_mat, hyb_flags;          // SPIRA_SEM_HYBRID: per-pixel ray state between its launches
     DevBuf spd32, spd64;                          // SPIRA_EXT_SPECTRAL: the SPD table, uploaded once per precision
@@ -120,7 +126,7 @@ struct Ctx {
     spira_counters last{};
     bool last_valid = false, last_pending = false;
     hipStream_t last_stream = nullptr;
-    std::mutex mu;
+    std::recursive_mutex mu;                  // (recursive: a host-output frame rendered as row slabs holds it across its slabs' render calls)
 };
 
 constexpr int kMaxDevices = 16;
@@ -151,7 +157,7 @@ int get_ctx(Ctx **out) {
     if (tl_device < 0 || tl_device >= n || tl_device >= kMaxDevices) return fail(SPIRA_E_INVALID, "device index out of range");
     Ctx &c = g_ctx[tl_device];
     HIP_TRY(hipSetDevice(tl_device));
-    std::lock_guard<std::mutex> init_lock(c.mu);     // two threads must not initialise one context twice
+    std::lock_guard<std::recursive_mutex> init_lock(c.mu);     // two threads must not initialise one context twice
     if (!c.init) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, tl_device));
@@ -503,6 +509,15 @@ int mark_done(Ctx &c, hipStream_t st) {
     return 0;
 }
 
+// The caller's output buffer is usually fresh from the allocator (`render` of either reference surface returns a new array): its pages do not exist yet,
+// and the first touch of 12 000 of them inside the copy costs 2-3 ms.  The threads that will move the frame in ask the kernel for the pages (writable,
+// contents untouched) while the GPU is still rendering; only pages that lie wholly inside the buffer.  A kernel that does not know the request says
+// EINVAL and the copy faults the pages in as before.
+void prefault_destination(char *p, size_t n) {
+    const uintptr_t pg = 4096, a = ((uintptr_t)p + pg - 1) & ~(pg - 1), b = ((uintptr_t)p + n) & ~(pg - 1);
+    if (b > a) (void)madvise((void *)a, b - a, 23 /* MADV_POPULATE_WRITE (Linux 5.14) */);
+}
+
 // A frame for a host-pointer caller (`render` of either reference surface returns a host array).  hipMemcpy into pageable memory runs at
 // ~9 GB/s on this box (the runtime stages it on one thread): 5.7 ms for a 1080p Float64 frame, as long as rendering it.  Instead: device ->
 // pinned staging in 8 MB chunks (one event each), and four host threads move the chunks on into the caller's memory as they arrive: 4.3 ms
@@ -543,8 +558,10 @@ int copy_out(Ctx &c, hipStream_t st, void *const dst[2], const void *const src[2
     }
     const int n_thr = (int)std::min<size_t>(std::max<uint32_t>(1, env_u32("SPIRA_STAGE_THREADS", 4)), pieces.size());
     std::vector<hipError_t> errs((size_t)n_thr, hipSuccess);
+    const bool prefault = env_u32("SPIRA_PREFAULT", 1) != 0;
     auto mover = [&](int t) {
         (void)hipSetDevice(c.device);
+        if (prefault) for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)n_thr) prefault_destination(pieces[i].dst, pieces[i].len);
         for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)n_thr) {
             const hipError_t e = hipEventSynchronize(c.stage_ev[i]);
             if (e != hipSuccess) { errs[(size_t)t] = e; return; }
@@ -562,8 +579,9 @@ int copy_out(Ctx &c, hipStream_t st, void *const dst[2], const void *const src[2
 // The scene of a call: host arrays (uploaded into the context's store) or a handle (already resident).
 template <class T>
 int acquire_scene(Ctx &c, hipStream_t st, const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10,
-                  const spira_params *p, spira::SceneGlobal<T> &g) {
+                  const spira_params *p, spira::SceneGlobal<T> &g, bool reuse = false) {
     if (h) { scene_pointers<T>(h->store, g); return 0; }
+    if (reuse) { scene_pointers<T>(c.scene, g); return 0; }      // (a later slab of the call that uploaded it)
     const uint32_t nt = triangles10 ? p->n_triangles : 0;
     if (int rc = scene_upload<T>(c.scene, st, c.have_done ? c.ev_done : nullptr, spheres5, materials8, triangles10, p->n_spheres, p->n_materials, nt)) return rc;
     scene_pointers<T>(c.scene, g);
@@ -659,14 +677,15 @@ int verify_path_args(const Ctx &c, const spira::PathArgs<T> &a, uint32_t first_l
 template <class T>
 int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
                 T *out_hdr, T *out_img, bool out_on_device, void *user_stream,
-                bool progressive = false, uint32_t sample0 = 0, uint32_t *rng_states = nullptr) {
+                bool progressive = false, uint32_t sample0 = 0, uint32_t *rng_states = nullptr, const SlabCtl *slab = nullptr) {
     // progressive: out_hdr is the caller's running SUM (in/out), samples [sample0, sample0 + spp) are added to it
     uint32_t rows = 0;
+    const bool cont = slab && slab->index > 0;      // a later slab of a host-output frame: continues slab 0's call (SlabCtl)
     if (!p) return fail(SPIRA_E_INVALID, "params is NULL");
     tl_lds_optin = hipSuccess;           // (a flag an earlier call of this thread left behind by returning early must not fail this one)
     Lap lap("render");
     if (h) { if (int rc = check_handle<T>(h)) return rc; }
-    else if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, triangles10 ? p->n_triangles : 0)) return rc;
+    else if (!cont) { if (int rc = validate_scene<T>(spheres5, materials8, triangles10, p->n_spheres, p->n_materials, triangles10 ? p->n_triangles : 0)) return rc; }
     if (int rc = validate_params(camera12, p, h ? h->store.nt : (triangles10 ? p->n_triangles : 0), &rows)) return rc;
     lap("validate");
     if (!out_hdr && !out_img) return fail(SPIRA_E_INVALID, "both outputs are NULL");
@@ -678,7 +697,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     Ctx *cp = nullptr;
     if (int rc = get_ctx(&cp)) return rc;
     Ctx &c = *cp;
-    std::lock_guard<std::mutex> lock(c.mu);
+    std::lock_guard<std::recursive_mutex> lock(c.mu);
     hipStream_t st = out_on_device ? (hipStream_t)user_stream : c.stream;
     if (int rc = order_after_previous(c, st)) return rc;
     lap("context");
@@ -759,7 +778,7 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
 
     lap("workspaces");
     spira::BounceArgs<T> a{};
-    if (int rc = acquire_scene<T>(c, st, h, spheres5, materials8, triangles10, p, a.scene)) return rc;
+    if (int rc = acquire_scene<T>(c, st, h, spheres5, materials8, triangles10, p, a.scene, cont)) return rc;
     if (int rc = attach_spd<T>(c, st, p, a.scene)) return rc;
     lap("scene");
     const bool scene_moderate = h ? h->store.moderate : c.scene.moderate;
@@ -784,13 +803,14 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     size_t n_prof = 0;
     if (profile) {
         n_prof = (size_t)n_pass * (persistent ? 1 : std::max<uint32_t>(p->max_depth, 1)) * 2;
-        if (int rc = profile_events(c, n_prof)) return rc;
+        if (int rc = profile_events(c, (cont ? c.ev_used : 0) + n_prof)) return rc;
     }
-    c.ev_used = 0;
-    c.ev_mid_used = 0;
-
-    HIP_TRY(hipMemsetAsync(c.stats.p, 0, sizeof(spira::Stats), st));
-    HIP_TRY(hipEventRecord(c.ev_start, st));
+    if (!cont) {                         // (a later slab adds its brackets and device counters to slab 0's)
+        c.ev_used = 0;
+        c.ev_mid_used = 0;
+        HIP_TRY(hipMemsetAsync(c.stats.p, 0, sizeof(spira::Stats), st));
+        HIP_TRY(hipEventRecord(c.ev_start, st));
+    }
     uint64_t launches = 0;
 
     // progressive accumulation: the caller's running sums (and, METAL, LCG states) seed the accumulator
@@ -1037,11 +1057,11 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
     HIP_TRY(hipMemcpyAsync(c.h_stats, c.stats.p, sizeof(spira::Stats), hipMemcpyDeviceToHost, st));
     lap("enqueue");
 
-    c.last = spira_counters{};
-    c.last.samples = (uint64_t)p->spp * tile_pixels;
-    c.last.passes = p->max_depth ? n_pass : 0;
-    c.last.launches = launches;
-    c.last.bounce_launches = metal_launches ? metal_launches : ((mega || !p->max_depth) ? 0 : (uint64_t)n_pass * (persistent ? 1 : p->max_depth));
+    if (!cont) c.last = spira_counters{};
+    c.last.samples += (uint64_t)p->spp * tile_pixels;
+    c.last.passes += p->max_depth ? n_pass : 0;
+    c.last.launches += launches;
+    c.last.bounce_launches += metal_launches ? metal_launches : ((mega || !p->max_depth) ? 0 : (uint64_t)n_pass * (persistent ? 1 : p->max_depth));
     c.last_valid = true;
     c.last_pending = true;
     c.last_stream = st;
@@ -1059,14 +1079,135 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
 
 // render_impl<T> of whichever translation unit holds the kernels of T
 template <class T>
+int render_entry_plain(const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
+                       T *out_hdr, T *out_img, bool out_on_device, void *user_stream, bool progressive = false, uint32_t sample0 = 0, uint32_t *rng_states = nullptr,
+                       const SlabCtl *slab = nullptr) {
+#ifdef SPIRA_TU_MAIN
+    if constexpr (sizeof(T) == 4)
+        return spira_tu::render_impl_f32(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states, slab);
+    else
+#endif
+        return render_impl<T>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states, slab);
+}
+
+#ifdef SPIRA_TU_MAIN
+// A large frame for a host-pointer caller, rendered as row slabs: slab k's planes go device -> pinned staging on a second stream while slab k + 1
+// renders, and the host threads of copy_out move them on into the caller's memory.  The copy of a 1080p frame (Float64 HDR: 49.8 MB, 5 ms into
+// pageable memory — as long as rendering it) then hides behind the kernels but for the last slab's share.  The RNG is keyed by the global pixel, so
+// the slabs are, bit for bit, the rows of the frame rendered whole (tests/test_gpu_runtime.py); the counters of the call add up over its slabs.
+// *done = false: the frame is not of that kind (small, striped, progressive, ...) and nothing was touched — the caller takes the plain path.
+template <class T>
+int render_host_slabs(const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
+                      T *out_hdr, T *out_img, bool *done) {
+    *done = false;
+    if (!p || !camera12 || (!out_hdr && !out_img)) return 0;
+    const uint32_t S_env = env_u32("SPIRA_HOST_SLABS", 0xFFFFFFFFu);                // (unset: chosen below; 0 or 1: never)
+    if (S_env < 2) return 0;
+    if ((p->flags & SPIRA_SEM_MASK) == SPIRA_SEM_HYBRID) return 0;                   // whole images only
+    if (p->rows != 0 && p->stripe_count > 1) return 0;                               // an interleaved tile (its rows are not consecutive image rows)
+    // a mesh pass ends with the tail of its fat waves, and four small passes have four of them: configs[4] 6.2 -> 7.8 ms of device time, more than the copy hides
+    if ((h ? h->store.nt : (triangles10 ? p->n_triangles : 0)) > SPIRA_LDS_TRIANGLES) return 0;
+    const uint32_t W = p->width, rows = p->rows ? p->rows : p->height, row0 = p->rows ? p->row0 : 0;
+    if (!W || !rows || !p->spp || (uint64_t)row0 + rows > p->height) return 0;      // (the plain path reports what is wrong)
+    const int n_out = (out_hdr ? 1 : 0) + (out_img ? 1 : 0);
+    const size_t plane3 = (size_t)3 * rows * W * sizeof(T), total = plane3 * (size_t)n_out;
+    // a slab costs ~0.1 ms of device time (its own launches and their tails) and hides its share of the copy: two for a 1080p Float32 image (24.9 MB: 4.7 -> 4.0 ms
+    // end to end), four from 32 MB on (1080p Float64 HDR, 49.8 MB: 7.3 -> 6.6 ms into touched memory; profiles/experiments/r04_host_slabs_probe.py)
+    const uint32_t S = S_env != 0xFFFFFFFFu ? std::min<uint32_t>(S_env, 16) : (total < ((size_t)32 << 20) ? 2u : 4u);
+    if (total < ((size_t)8 << 20) || total > ((size_t)512 << 20) || rows < 16 * S || (uint64_t)rows * W * p->spp < ((uint64_t)16 << 20)) return 0;
+    Ctx *cp = nullptr;
+    if (int rc = get_ctx(&cp)) return rc;
+    Ctx &c = *cp;
+    std::lock_guard<std::recursive_mutex> lock(c.mu);
+    if (c.h_stage_cap < total) {
+        if (c.h_stage) { (void)hipHostFree(c.h_stage); c.h_stage = nullptr; c.h_stage_cap = 0; }
+        if (hipHostMalloc(&c.h_stage, total, hipHostMallocDefault) == hipSuccess) c.h_stage_cap = total;
+        else { c.h_stage = nullptr; (void)hipGetLastError(); return 0; }                // no pinned memory to be had: the plain path still works
+    }
+    if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+    if (!c.ev_slab) HIP_TRY(hipEventCreateWithFlags(&c.ev_slab, hipEventDisableTiming));
+    if (int rc = order_after_previous(c, c.stream)) return rc;                       // (out_tmp may still be read by the previous call)
+    if (int rc = c.out_tmp.ensure(2 * plane3)) return rc;
+    *done = true;
+    Lap lap("host slabs");
+    struct Piece { char *dst; size_t off, len; };
+    std::vector<Piece> pieces;
+    size_t off = 0;
+    int rc_all = 0;
+    for (uint32_t s = 0, r0 = 0; s < S && !rc_all; ++s) {
+        const uint32_t rs = rows / S + (s < rows % S ? 1u : 0u);
+        spira_params ps = *p;
+        ps.row0 = row0 + r0; ps.rows = rs; ps.stripe_h = 0; ps.stripe_count = 0; ps.stripe_rank = 0;
+        // the slab's planar block [3][rs][W] sits at element 3 * W * r0 of its output's device frame
+        T *d_hdr = out_hdr ? (T *)c.out_tmp.p + (size_t)3 * W * r0 : nullptr;
+        T *d_img = out_img ? (T *)((char *)c.out_tmp.p + plane3) + (size_t)3 * W * r0 : nullptr;
+        const SlabCtl ctl{s, S};
+        rc_all = render_entry_plain<T>(h, spheres5, materials8, triangles10, camera12, &ps, d_hdr, d_img, true, (void *)c.stream, false, 0, nullptr, &ctl);
+        if (rc_all) break;
+        hipError_t e = hipEventRecord(c.ev_slab, c.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c.copy_stream, c.ev_slab, 0);
+        T *const dev[2] = {d_hdr, d_img};
+        T *const host[2] = {out_hdr, out_img};
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            if (!host[k]) continue;
+            for (int pl = 0; pl < 3 && e == hipSuccess; ++pl) {
+                const size_t len = (size_t)rs * W * sizeof(T);
+                e = hipMemcpyAsync((char *)c.h_stage + off, dev[k] + (size_t)pl * rs * W, len, hipMemcpyDeviceToHost, c.copy_stream);
+                if (e != hipSuccess) break;
+                if (c.stage_ev.size() <= pieces.size()) {
+                    hipEvent_t ev;
+                    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                    if (e != hipSuccess) break;
+                    c.stage_ev.push_back(ev);
+                }
+                e = hipEventRecord(c.stage_ev[pieces.size()], c.copy_stream);
+                pieces.push_back({(char *)(host[k] + ((size_t)pl * rows + r0) * W), off, len});
+                off += len;
+            }
+        }
+        if (e != hipSuccess) rc_all = fail(SPIRA_E_HIP, std::string("host-output slabs: ") + hipGetErrorString(e));
+        r0 += rs;
+    }
+    if (rc_all) {                        // drain what was enqueued; nothing of the frame is promised
+        (void)hipStreamSynchronize(c.stream); (void)hipStreamSynchronize(c.copy_stream);
+        return rc_all;
+    }
+    lap("enqueue");
+    const int n_thr = (int)std::min<size_t>(std::max<uint32_t>(1, env_u32("SPIRA_STAGE_THREADS", 4)), pieces.size());
+    std::vector<hipError_t> errs((size_t)n_thr, hipSuccess);
+    const bool prefault = env_u32("SPIRA_PREFAULT", 1) != 0;
+    auto mover = [&](int t) {
+        (void)hipSetDevice(c.device);
+        if (prefault) for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)n_thr) prefault_destination(pieces[i].dst, pieces[i].len);
+        for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)n_thr) {
+            const hipError_t e = hipEventSynchronize(c.stage_ev[i]);
+            if (e != hipSuccess) { errs[(size_t)t] = e; return; }
+            std::memcpy(pieces[i].dst, (const char *)c.h_stage + pieces[i].off, pieces[i].len);
+        }
+    };
+    std::vector<std::thread> thr;
+    for (int t = 1; t < n_thr; ++t) thr.emplace_back(mover, t);
+    mover(0);
+    for (auto &t : thr) t.join();
+    lap("movers");
+    HIP_TRY(hipStreamSynchronize(c.copy_stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    for (hipError_t e : errs) if (e != hipSuccess) return fail(SPIRA_E_HIP, std::string("host-output slabs: ") + hipGetErrorString(e));
+    return 0;
+}
+#endif
+
+template <class T>
 int render_entry(const spira_scene *h, const T *spheres5, const T *materials8, const T *triangles10, const T *camera12, const spira_params *p,
                  T *out_hdr, T *out_img, bool out_on_device, void *user_stream, bool progressive = false, uint32_t sample0 = 0, uint32_t *rng_states = nullptr) {
 #ifdef SPIRA_TU_MAIN
-    if constexpr (sizeof(T) == 4)
-        return spira_tu::render_impl_f32(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
-    else
+    if (!out_on_device && !progressive) {
+        bool done = false;
+        const int rc = render_host_slabs<T>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, &done);
+        if (done || rc) return rc;
+    }
 #endif
-        return render_impl<T>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
+    return render_entry_plain<T>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
 }
 
 template <class T>
@@ -1086,7 +1227,7 @@ int trace_impl(const T *spheres5, const T *materials8, const T *triangles10, con
     Ctx *cp = nullptr;
     if (int rc = get_ctx(&cp)) return rc;
     Ctx &c = *cp;
-    std::lock_guard<std::mutex> lock(c.mu);
+    std::lock_guard<std::recursive_mutex> lock(c.mu);
     hipStream_t st = c.stream;
     if (int rc = order_after_previous(c, st)) return rc;
     spira::BounceArgs<T> a{};
@@ -1356,7 +1497,7 @@ int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materia
             Ctx &c = *cp;
             st = c.stream;
             {
-                std::lock_guard<std::mutex> lock(c.mu);
+                std::lock_guard<std::recursive_mutex> lock(c.mu);
                 if (int rc = c.multi_tile.ensure(2 * tile_elems * sizeof(T))) return rc;      // the tile + a scratch copy for ragged tiles
                 if (r == 0 || rehearse) {
                     if (int rc = c.multi_stack.ensure((size_t)n * tile_elems * sizeof(T))) return rc;
@@ -1413,12 +1554,12 @@ int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materia
             void *const dst[2] = {out_hdr, out_img};
             const void *const src[2] = {c.multi_full.p, (const char *)c.multi_full.p + plane3};
             {
-                std::lock_guard<std::mutex> lock(c.mu);          // (the staging buffer belongs to the context)
+                std::lock_guard<std::recursive_mutex> lock(c.mu);          // (the staging buffer belongs to the context)
                 if (int rc = copy_out(c, st, dst, src, plane3)) return bail(rc);
             }
         }
         {
-            std::lock_guard<std::mutex> lock(c.mu);
+            std::lock_guard<std::recursive_mutex> lock(c.mu);
             if (int rc = mark_done(c, st)) return bail(rc);
         }
         hipError_t he = hipStreamSynchronize(st);
@@ -1453,8 +1594,8 @@ void spira_tu::launch_path_resume_f64(int R, dim3 grid, size_t lds, hipStream_t 
 }
 #elif defined(SPIRA_TU_F32)
 int spira_tu::render_impl_f32(const spira_scene *h, const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
-                              float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states) {
-    return render_impl<float>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states);
+                              float *out_hdr, float *out_img, bool out_on_device, void *user_stream, bool progressive, uint32_t sample0, uint32_t *rng_states, const SlabCtl *slab) {
+    return render_impl<float>(h, spheres5, materials8, triangles10, camera12, p, out_hdr, out_img, out_on_device, user_stream, progressive, sample0, rng_states, slab);
 }
 int spira_tu::trace_impl_f32(const float *spheres5, const float *materials8, const float *triangles10, const float *camera12, const spira_params *p,
                              uint32_t n_paths, const uint32_t *ijs, int *prims, float *ts, float *dirs, float *radiance) {
@@ -1500,7 +1641,7 @@ int spira_get_counters(spira_counters *out) {
     Ctx *cp = nullptr;
     if (int rc = get_ctx(&cp)) return rc;
     Ctx &c = *cp;
-    std::lock_guard<std::mutex> lock(c.mu);
+    std::lock_guard<std::recursive_mutex> lock(c.mu);
     if (!c.last_valid) return fail(SPIRA_E_INVALID, "no render has run on this device");
     if (c.last_pending) {
         HIP_TRY(hipEventSynchronize(c.ev_stop));
@@ -1540,7 +1681,7 @@ void spira_shutdown(void) {
     { std::lock_guard<std::mutex> rl(g_rccl.mu); if (g_rccl.handle) rccl_release(g_rccl); }
     for (int d = 0; d < kMaxDevices; ++d) {
         Ctx &c = g_ctx[d];
-        std::lock_guard<std::mutex> lock(c.mu);
+        std::lock_guard<std::recursive_mutex> lock(c.mu);
         if (!c.init) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
@@ -1558,6 +1699,8 @@ void spira_shutdown(void) {
         for (hipEvent_t e : c.stage_ev) (void)hipEventDestroy(e);
         c.stage_ev.clear();
         (void)hipStreamDestroy(c.stream);
+        if (c.copy_stream) { (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
+        if (c.ev_slab) { (void)hipEventDestroy(c.ev_slab); c.ev_slab = nullptr; }
         c.init = false; c.last_valid = false;
     }
 }

@@ -235,3 +235,37 @@ def test_plain_flags_library():
             "assert B.LIB_PATH.endswith('libspira_hip_plain.so') and B.build_id() == 'plain-flags', (B.LIB_PATH, B.build_id()); g.smoke()" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SPIRA_HIP_LIB=lib), timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_host_output_frames_render_as_row_slabs(gpu, monkeypatch):
+    """A large frame for a host-pointer caller is rendered as 4 row slabs so that a slab's copy to the host runs beside the next slab's kernels
+    (spira_hip.hip, render_host_slabs).  The slabs are, bit for bit, the rows of the frame rendered whole (SPIRA_HOST_SLABS=0), for every organisation,
+    row order, output selection and a sub-tile; and the call's counters add up over its slabs."""
+    from spira_hip import _binding as B
+    cases = [
+        (scenes.scene_s1, "f64", 1024, 512, 32, 6, dict(flags=B.KERNEL_WAVEFRONT), True, True),
+        (scenes.scene_s1, "f32", 1536, 768, 16, 5, dict(flags=B.KERNEL_WAVEFRONT | B.ROWS_BOTTOM_UP | B.POST_ACES_GAMMA), False, True),     # display image only
+        (scenes.scene_s3, "f32", 1536, 770, 16, 4, dict(flags=B.KERNEL_MEGA), True, True),                                                # rows % 4 != 0
+        (scenes.scene_s2, "f64", 1024, 600, 32, 4, dict(flags=B.KERNEL_BOUNCE, row0=37, rows=523), True, False),                          # a sub-tile, HDR only
+        (lambda: scenes.scene_s4(level=3), "f32", 1536, 768, 16, 6, dict(flags=B.KERNEL_WAVEFRONT), True, True),                          # mesh: two launches per pass
+        (scenes.scene_s1, "f64", 1024, 512, 32, 4, dict(flags=B.KERNEL_WAVEFRONT | B.SEM_METAL), True, True),
+    ]
+    for mk, prec, W, H, spp, depth, kw, want_hdr, want_img in cases:
+        s = mk()
+        ns, nm, nt = _counts(s)
+        p = gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=12, **kw)
+        out = {}
+        for slabs in ("0", "4"):
+            monkeypatch.setenv("SPIRA_HOST_SLABS", slabs)
+            hdr, img = gpu.render(*_args(s), p, prec, want_hdr=want_hdr, want_img=want_img)
+            out[slabs] = (hdr, img, gpu.counters())
+        (h0, i0, c0), (h4, i4, c4) = out["0"], out["4"]
+        if want_hdr:
+            assert np.array_equal(h0, h4), (mk, prec)
+        if want_img:
+            assert np.array_equal(i0, i4), (mk, prec)
+        for k in ("samples", "segments", "rays_parked", "radiance_stores", "radiance_rmw"):      # (what is queued depends on who shares a wave: not an invariant)
+            assert c0[k] == c4[k], (k, c0[k], c4[k])
+        # (mesh scenes are never split: four small mesh passes have four fat-wave tails, more than the copy hides)
+        n_slabs = 1 if nt > 32 else 4
+        assert c4["passes"] == n_slabs * c0["passes"] and (c4["launches"] > c0["launches"]) == (n_slabs > 1) and c4["kernel_ms"] > 0
