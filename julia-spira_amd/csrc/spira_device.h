@@ -852,8 +852,11 @@ __device__ __forceinline__ void bvh_closest_hit(const SceneLds<T> &sc, Vec<T> o,
 // The LDS-resident part of the scan (spheres, then the small triangle set); `closest` / `prim` come in as "nothing yet" and go out updated.
 // TRI = false: an instantiation for scenes without LDS-resident triangles (spheres only, or spheres + a BVH mesh) — the triangle scan and
 // the triangle arms of the shading code are not compiled in, which is worth 3 % on S1 in Float64 through register allocation alone.
-template <class T, class P, bool TRI = true>
-__device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, P &pol) {
+// CAM = true (camera rays of k_path): every camera ray starts at the camera's origin, so `oc` (:114) and `dot(oc, oc) - radius^2` (:117) of a sphere are the
+// same for all of them — `cam[s]` holds them {oc.x, oc.y, oc.z, c}, evaluated once per workgroup by the same operations on the same values (same bits),
+// and the ray is left with half the arithmetic of a sphere test (9 of 18 operations).
+template <class T, class P, bool TRI = true, bool CAM = false>
+__device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> o, Vec<T> d, T t_min, T &closest, int &prim, P &pol, const Pack4<T> *cam = nullptr) {
     closest = (T)INFINITY;                                     // t_max = Inf, :335
     prim = -1;
     const T a = dot(d, d);                                     // :115 (same value for every sphere)
@@ -863,14 +866,19 @@ __device__ __forceinline__ void closest_hit_local(const SceneLds<T> &sc, Vec<T> 
     root_t_min<T>(t_min, pol);
     // software-pipelined LDS reads: the next sphere's packet is requested before this one is tested, so the
     // ds_read latency overlaps the arithmetic instead of stalling every iteration at s_waitcnt lgkmcnt(0)
-    Pack4<T> c_next = sc.sph[0];           // (slot 0 always exists in the LDS image: the block is never empty)
+    const Pack4<T> *sph = CAM ? cam : sc.sph;
+    Pack4<T> c_next = sph[0];              // (slot 0 always exists in the LDS image: the block is never empty)
 #pragma unroll 2       // two tests per trip: the packet rotation (c = c_next) turns into register renaming, +1..3 %
     for (uint32_t s = 0; s < sc.n_spheres; ++s) {
         const Pack4<T> c = c_next;
-        c_next = sc.sph[s + 1 < sc.n_spheres ? s + 1 : s];
-        Vec<T> oc = o - mk<T>(c.x, c.y, c.z);                  // :114
+        c_next = sph[s + 1 < sc.n_spheres ? s + 1 : s];
+        Vec<T> oc; T cc;
+        if (CAM) { oc = mk<T>(c.x, c.y, c.z); cc = c.w; }
+        else {
+            oc = o - mk<T>(c.x, c.y, c.z);                     // :114
+            cc = dot(oc, oc) - c.w;                            // :117
+        }
         T b = (T)2.0 * dot(oc, d);                             // :116
-        T cc = dot(oc, oc) - c.w;                              // :117
         const T bb = b * b;
         T disc = bb - four_a * cc;                             // :118
         if (!(disc < 0)) {                                     // :120
@@ -1433,6 +1441,7 @@ template <class T> struct PathArgs {
     RayQueue<T> q[2];                // stage k writes q[k & 1] and (k >= 1) reads q[(k + 1) & 1]
     uint32_t *qref[2];               // Float32 only: the hit reference of each queued packet (Float64 packs it beside q)
     uint2 *qkey[2];                  // sphere scenes without extensions: the path's half-made RNG key beside each packet (k_path, kCarry)
+    uint32_t cam_consts;             // the launch's LDS block has room for one packet per sphere behind the camera: the camera rays' share of a sphere test (closest_hit_local, CAM)
     Pack3<T> *L;                     // per-path radiance of the pass batch (slot-major)
     uint32_t *blk_stats;             // [NW][4] segments, radiance RMWs, radiance stores, packets enqueued
     uint32_t cap;                    // region size in packets (a multiple of R*64)
@@ -1516,6 +1525,14 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
         const uint32_t cc = threadIdx.x % 3;
         cam_lds[threadIdx.x] = cc == 0 ? cv->x : (cc == 1 ? cv->y : cv->z);
     }
+    Pack4<T> *cam_sph = reinterpret_cast<Pack4<T> *>(reinterpret_cast<unsigned char *>(cam_lds) + 128);
+    if (MODE != 2 && a.cam_consts)                               // (the second launch of a mesh pass has no camera rays)
+        for (uint32_t i = threadIdx.x; i < a.scene.n_spheres; i += blockDim.x) {
+            const T *sp = a.scene.spheres5 + 5 * (size_t)i;
+            const Vec<T> oc = rc.cam_origin - mk<T>(sp[0], sp[1], sp[2]);         // :114 with the origin every camera ray has
+            Pack4<T> k; k.x = oc.x; k.y = oc.y; k.z = oc.z; k.w = dot(oc, oc) - sp[3] * sp[3];      // :117 (radius*radius as stage_scene makes it)
+            cam_sph[i] = k;
+        }
     const SceneLds<T> sc = stage_scene<T>(a.scene, lds_raw);     // the only workgroup barrier of the kernel
     const PixelDiv<T> pix_div = pixel_divisors<T>(rc);
     if (!SPEC && a.redo_only) {
@@ -1614,9 +1631,11 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                         T t; uint32_t slot = 0;
                         int prim;
                         if (defer) {
-                            closest_hit_local<T, Pol, TRI>(sc, o[r], d, (T)0.001, t, prim, pol);       // :335, spheres and LDS triangles
+                            if (a.cam_consts) closest_hit_local<T, Pol, TRI, true>(sc, o[r], d, (T)0.001, t, prim, pol, cam_sph);
+                            else closest_hit_local<T, Pol, TRI>(sc, o[r], d, (T)0.001, t, prim, pol);   // :335, spheres and LDS triangles
                             parked = mesh_box_hit<T>(sc, o[r], d, t);
-                        } else prim = closest_hit<T, BVH, Pol, TRI>(sc, o[r], d, (T)0.001, t, slot, pol);     // :335
+                        } else if (!BVH && a.cam_consts) { closest_hit_local<T, Pol, TRI, true>(sc, o[r], d, (T)0.001, t, prim, pol, cam_sph); }
+                        else prim = closest_hit<T, BVH, Pol, TRI>(sc, o[r], d, (T)0.001, t, slot, pol);     // :335
                         ++n_seg;
                         if (parked) { park_t = t; park_prim = prim; pend[r].v = d; }          // parked below, in uniform control flow
                         else if (prim < 0) {                      // the camera ray leaves the scene: sky, :365-366

@@ -981,7 +981,10 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 pa.mesh_mode = 0; pa.mesh_count = nullptr; pa.resume_k = 1; pa.resume_nw = 0;
                 pa.mesh_min_batch = std::max<uint32_t>(1, env_u32("SPIRA_MESH_MIN_BATCH", 128));
                 pa.refill_free = std::min<uint32_t>(64, std::max<uint32_t>(1, env_u32("SPIRA_MESH_REFILL", 16)));
-                const size_t lds_a = lds + (size_t)wpb * sub * sizeof(P4) + 128;       // + one work list per wave + the camera
+                size_t lds_a = lds + (size_t)wpb * sub * sizeof(P4) + 128;             // + one work list per wave + the camera
+                // ... + one packet per sphere: what a sphere test of a CAMERA ray does not depend on the ray for (closest_hit_local, CAM) — where the block has the room
+                pa.cam_consts = (env_u32("SPIRA_CAM_CONSTS", 1) && a.scene.n_spheres && lds_a + (size_t)a.scene.n_spheres * sizeof(P4) <= (size_t)160 * 1024) ? 1u : 0u;
+                if (pa.cam_consts) lds_a += (size_t)a.scene.n_spheres * sizeof(P4);
                 if (plan.two_pass) {
                     pa.mesh_mode = 1; pa.mesh_count = (uint32_t *)c.mesh_count.p;
                     // the fat waves of the second launch: about 16 per CU (4 per SIMD), each taking over k <= 16 first-launch waves; k divides their number

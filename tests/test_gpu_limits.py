@@ -39,6 +39,25 @@ def test_carried_rng_key_depth_boundary(gpu, oracle, prec):
             assert _close(hdr, ohdr)[0] == 0 and gpu.counters()["segments"] == oseg, (mk.__name__, depth)
 
 
+def test_camera_ray_sphere_constants(gpu, oracle, monkeypatch):
+    """Camera rays share their origin, so k_path keeps what a sphere test does not need the direction for in LDS, one packet per sphere (closest_hit_local,
+    CAM) — where the launch's LDS block has the room.  With the packets, without them (SPIRA_CAM_CONSTS=0), and on a scene so large that they do not fit
+    (1024 spheres + 1180 materials in Float64: 163 KB with them): the same bits, and the oracle's."""
+    from test_gpu_parity import random_scene
+    rng = np.random.default_rng(31)
+    big = random_scene(rng, 1024, 0, n_mats=1180)
+    for s, prec, (W, H, spp, depth), fits in [(scenes.scene_s1(), "f64", (64, 36, 3, 5), True), (random_scene(rng, 300, 20), "f32", (48, 27, 2, 4), True),
+                                              (scenes.scene_s4(level=2), "f64", (48, 27, 2, 5), True), (big, "f64", (24, 14, 1, 3), False)]:
+        ns, nm, nt = _counts(s)
+        out = {}
+        for on in ("1", "0"):
+            monkeypatch.setenv("SPIRA_CAM_CONSTS", on)
+            out[on], _ = gpu.render(*_args(s), gpu.make_params(W, H, spp, depth, ns, nm, nt, seed=17), prec)
+        ohdr, _, oseg = oracle.render(*_args(s), oracle.make_params(W, H, spp, depth, ns, nm, nt, seed=17), prec)
+        assert np.array_equal(out["1"], out["0"]), (ns, prec, fits)
+        assert _close(out["1"], ohdr)[0] == 0 and gpu.counters()["segments"] == oseg, (ns, prec)
+
+
 def test_4k_frame_runs_and_matches_tiles(gpu):
     """3840x2160 (8.3 M pixels): several slots per pass; the top half rendered as a slab equals the full frame's top half."""
     s = scenes.scene_s1()
