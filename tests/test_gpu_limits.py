@@ -41,13 +41,13 @@ def test_carried_rng_key_depth_boundary(gpu, oracle, prec):
 
 def test_camera_ray_sphere_constants(gpu, oracle, monkeypatch):
     """Camera rays share their origin, so k_path keeps what a sphere test does not need the direction for in LDS, one packet per sphere (closest_hit_local,
-    CAM) — where the launch's LDS block has the room.  With the packets, without them (SPIRA_CAM_CONSTS=0), and on a scene so large that they do not fit
-    (1024 spheres + 1180 materials in Float64: 163 KB with them): the same bits, and the oracle's."""
+    CAM) — where the launch's LDS block has the room.  With the packets, without them (SPIRA_CAM_CONSTS=0), on a scene that just leaves the room (1024 spheres +
+    1180 materials in Float64: 163 488 of 163 840 bytes with them) and on one that does not (1250 materials: 167 968): the same bits, and the oracle's."""
     from test_gpu_parity import random_scene
     rng = np.random.default_rng(31)
-    big = random_scene(rng, 1024, 0, n_mats=1180)
     for s, prec, (W, H, spp, depth), fits in [(scenes.scene_s1(), "f64", (64, 36, 3, 5), True), (random_scene(rng, 300, 20), "f32", (48, 27, 2, 4), True),
-                                              (scenes.scene_s4(level=2), "f64", (48, 27, 2, 5), True), (big, "f64", (24, 14, 1, 3), False)]:
+                                              (scenes.scene_s4(level=2), "f64", (48, 27, 2, 5), True), (random_scene(rng, 1024, 0, n_mats=1180), "f64", (24, 14, 1, 3), True),
+                                              (random_scene(rng, 1024, 0, n_mats=1250), "f64", (24, 14, 1, 3), False)]:
         ns, nm, nt = _counts(s)
         out = {}
         for on in ("1", "0"):
