@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
     const uint32_t region = wid * kseg * a.cap;                  // (a fat wave owns the regions of the k waves it takes over)
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t ref_base = sc.n_spheres + sc.n_triangles;     // references >= ref_base are BVH triangle slots
-    // Dense continuation (a.dense_pct > 0, max_depth <= 128; host default 80 %): when at least dense_pct % of a
+    // Dense continuation (a.dense_pct > 0, max_depth <= 128; host default 70 %): when at least dense_pct % of a
     // sub-chunk's scattered rays hit again, they
     // stay in registers and go straight into their next stage instead of through the queue — compaction only where it pays (a closed
     // scene never touches the queues; an open one compacts as before).  Packets then carry their own stage (7 bits above the hit

@@ -959,7 +959,9 @@ int render_impl(const spira_scene *h, const T *spheres5, const T *materials8, co
                 // dense continuation threshold (same device, S1 1080p spp 64 depth 8, Msamples/s): f64 100 %: 20 218, 90: 20 563, 80: 20 953,
                 // 70: 20 963, 60: 20 052; f32 90: 30 222, 80: 30 141, 70: 29 567, 60: 28 354 — a packet costs twice the bytes in Float64, so it
                 // pays to keep a little more in registers there.  On the closed box S3 any threshold > 0 gives the full +22 % (f64).
-                pa.dense_pct = std::min<uint32_t>(env_u32("SPIRA_DENSE_PCT", 80), 100);      // (Float32 re-measured on the no-SLP build, S1: 90: 37 900, 85: 38 500, 80: 38 500, 75: 38 500, 70: 37 500)
+                // Round 4 (packets carry the RNG key words: a queued hit costs more), S1 ms per frame, two rounds on one box: f64 80: 5.302 / 5.277, 75: 5.245 / 5.229,
+                // 70: 5.221 / 5.240, 65: 5.272 / 5.299; f32 80: 3.382 / 3.414, 75: 3.341 / 3.354, 70: 3.340 / 3.351, 65: 3.374 / 3.351; configs[4] the same at 70 and 80.
+                pa.dense_pct = std::min<uint32_t>(env_u32("SPIRA_DENSE_PCT", 70), 100);      // (Float32 re-measured on the no-SLP build of round 3, S1: 90: 37 900, 85: 38 500, 80: 38 500, 75: 38 500, 70: 37 500)
                 // BVH scenes: the wave-owned lists of rays waiting for their dense traversal batch (3 packets per entry, `cap` entries per wave)
                 pa.mesh_list = plan.mesh ? (P4 *)c.mesh_list.p : nullptr;
                 geometry(n_first, G, pa.cap);
