@@ -1526,7 +1526,9 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
         cam_lds[threadIdx.x] = cc == 0 ? cv->x : (cc == 1 ? cv->y : cv->z);
     }
     Pack4<T> *cam_sph = reinterpret_cast<Pack4<T> *>(reinterpret_cast<unsigned char *>(cam_lds) + 128);
-    if (MODE != 2 && a.cam_consts)                               // (the second launch of a mesh pass has no camera rays)
+    // (not in the extension instantiations: the second copy of the camera rays' scan costs the Float64 one 140 bytes of scratch per lane — glass scene 5.8 -> 6.6 ms)
+    constexpr bool kCam = !EXT;
+    if (kCam && MODE != 2 && a.cam_consts)                       // (the second launch of a mesh pass has no camera rays)
         for (uint32_t i = threadIdx.x; i < a.scene.n_spheres; i += blockDim.x) {
             const T *sp = a.scene.spheres5 + 5 * (size_t)i;
             const Vec<T> oc = rc.cam_origin - mk<T>(sp[0], sp[1], sp[2]);         // :114 with the origin every camera ray has
@@ -1631,10 +1633,10 @@ __global__ __launch_bounds__(kBlock, MODE == 2 ? (sizeof(T) == 8 ? SPIRA_WAVES_B
                         T t; uint32_t slot = 0;
                         int prim;
                         if (defer) {
-                            if (a.cam_consts) closest_hit_local<T, Pol, TRI, true>(sc, o[r], d, (T)0.001, t, prim, pol, cam_sph);
+                            if (kCam && a.cam_consts) closest_hit_local<T, Pol, TRI, true>(sc, o[r], d, (T)0.001, t, prim, pol, cam_sph);
                             else closest_hit_local<T, Pol, TRI>(sc, o[r], d, (T)0.001, t, prim, pol);   // :335, spheres and LDS triangles
                             parked = mesh_box_hit<T>(sc, o[r], d, t);
-                        } else if (!BVH && a.cam_consts) { closest_hit_local<T, Pol, TRI, true>(sc, o[r], d, (T)0.001, t, prim, pol, cam_sph); }
+                        } else if (kCam && !BVH && a.cam_consts) { closest_hit_local<T, Pol, TRI, true>(sc, o[r], d, (T)0.001, t, prim, pol, cam_sph); }
                         else prim = closest_hit<T, BVH, Pol, TRI>(sc, o[r], d, (T)0.001, t, slot, pol);     // :335
                         ++n_seg;
                         if (parked) { park_t = t; park_prim = prim; pend[r].v = d; }          // parked below, in uniform control flow
