@@ -29,7 +29,8 @@ def test_default_line_has_the_contract_keys_and_is_consistent():
     assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
-    assert r["avg_launch_ms"] * r["launches"] <= d["ms_per_step"] * 1.02          # the kernel fits inside the step it was timed in
+    # the kernel fits inside the step it was timed in (its events bracket the LAST timed step, ms_per_step is the mean of all: 5 % for the step-to-step spread)
+    assert r["avg_launch_ms"] * r["launches"] <= d["ms_per_step"] * 1.05
     assert abs(d["value"] - d["config"]["samples_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
     if r["traffic"] is None:                              # PMC figures of other kernel sources never reach the line
         assert r["traffic_stale"] in (True, False) and r["valu"] is None
