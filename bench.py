@@ -4,7 +4,7 @@
 A "step" is one whole render of the workload.  At N=1 the workload is BASELINE configs[2]:
 1920x1080, spp=64, max_depth=8 on the reference's own scene (create_scene() of
 src/spira-metal-optimized.jl:429-510 with main()'s camera :1499-1505), synthetic by construction.
-At N>1 the frame is tile-sharded over the ranks (interleaved 8-row stripes, one process per GPU,
+At N>1 the frame is tile-sharded over the ranks (interleaved rows, one process per GPU,
 no collective while rendering, ONE RCCL gather of the tiles per step) and spp = 64*N, so the
 per-GPU work is fixed ("weak").  `--config c4` is BASELINE configs[3] instead: spp 256 in TOTAL at any
 N ("strong"); `--config c5` is configs[4] (mesh scene, depth 12).  The scene is resident in HBM (a scene handle, created before the
@@ -522,7 +522,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
             "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "%s: %dx%d spp=%d depth=%d, scene %s (%s), semantics A, %s kernel organisation, tile-sharded "
-                                   "over %d GPU(s) in 8-row stripes + one RCCL gather" %
+                                   "over %d GPU(s), rows dealt round-robin + one RCCL gather" %
                                    (cfg["name"], W, H, spp_total, depth, scene_name, SCENE_DESC[scene_name], args.kernel, world),
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": scene_name, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],

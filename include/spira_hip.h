@@ -211,7 +211,7 @@ int spira_render_device_f64(const double *spheres5, const double *materials8, co
 
 /* ---- multi-device render on ONE node ----
  * Replaces the backend branch of render (src/spira-metal-optimized.jl:1460-1479) for a host that owns several GPUs: the
- * frame is dealt to devices 0..n_devices-1 as interleaved 8-row stripes (spira_params "Tiling"; the RNG is keyed by the
+ * frame is dealt to devices 0..n_devices-1 as interleaved single rows (spira_params "Tiling"; the RNG is keyed by the
  * global pixel, so the result is bit-identical to a one-device render), each device renders its tile on its own stream
  * driven by its own host thread inside the library, no collective runs while rendering, and ONE RCCL exchange (grouped
  * ncclSend / ncclRecv = a gather; n-1 point-to-point transfers over xGMI that arrive at device 0 at once) brings the tiles

@@ -1437,7 +1437,7 @@ __global__ void k_assemble(const T *stack, T *full, uint32_t n, uint32_t stripe_
     }
 }
 
-constexpr uint32_t kMultiStripeH = 8;
+constexpr uint32_t kMultiStripeH = 1;      // (single rows: equal tiles whatever the height; 8-row stripes cost a world-8 rank 4 % — distributed.py)
 
 // `mh`: a scene resident on the devices (spira_scene_create_multi_*) — nothing is validated, hashed, built or uploaded per call — or NULL: host arrays
 template <class T>
@@ -1466,7 +1466,7 @@ int render_multi_impl(const spira_scene *mh, const T *spheres5, const T *materia
         if (int rc = validate_params(camera12, p, nt, &rows)) return rc;
     }
     const uint32_t n = (uint32_t)n_devices, W = p->width, H = p->height;
-    if (stripe_rows(H, kMultiStripeH, n, n - 1) == 0) return fail(SPIRA_E_INVALID, "image has fewer 8-row stripes than devices");
+    if (stripe_rows(H, kMultiStripeH, n, n - 1) == 0) return fail(SPIRA_E_INVALID, "image has fewer rows than devices");
     const uint32_t max_rows = stripe_rows(H, kMultiStripeH, n, 0);
     const size_t tile_elems = (size_t)6 * max_rows * W;                 // hdr planes + img planes, padded to the largest tile
     std::lock_guard<std::mutex> rl(g_rccl.mu);                           // one multi-device render at a time

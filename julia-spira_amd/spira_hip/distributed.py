@@ -7,7 +7,9 @@ size / stripe height (tests/test_distributed_cpu.py, tests/test_gpu_parity.py).
 """
 import numpy as np
 
-DEFAULT_STRIPE_H = 8
+# Single rows: every rank gets height / world rows +- 1 whatever the height.  (8-row stripes until round 4: at world 8 a rank's tile then cost 4 % more than
+# an eighth of the frame — ragged 128 / 136 rows and, row for row, slower launches; profiles/experiments/r04_stripe_height_sweep.py.)
+DEFAULT_STRIPE_H = 1
 _plans = {}
 
 

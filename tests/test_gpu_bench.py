@@ -72,6 +72,6 @@ def test_two_ranks_launched_the_driver_way_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["spp"] == 128 and "spp=128" in d["metric"]
     assert d["config"]["samples_per_step"] == 1920 * 1080 * 128 and d["cpu_baseline"] is None and d["configs"] is None
     p = d["per_rank"]
-    assert p["rows_per_rank"] == {"max": 544, "min": 536}                 # 135 stripes of 8 rows dealt to 2 ranks: 68 and 67
+    assert p["rows_per_rank"] == {"max": 540, "min": 540}                 # 1080 rows dealt row by row to 2 ranks
     assert 0 < p["render_ms"]["min"] <= p["render_ms"]["max"] <= d["ms_per_step"] * 1.05 and p["gather_ms"]["max"] > 0
     assert abs(d["value"] - d["config"]["samples_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3

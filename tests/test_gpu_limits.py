@@ -78,7 +78,7 @@ def test_small_batches_many_passes(gpu):
 
 
 def test_config4_full_size_shard_equals_frame_rows(gpu):
-    """BASELINE configs[3] (1920x1080, spp 256, depth 8, 8 GPUs): what rank 3 of 8 renders (its interleaved 8-row stripes) is,
+    """BASELINE configs[3] (1920x1080, spp 256, depth 8, 8 GPUs): what rank 3 of 8 renders (rows 3, 11, 19, ...) is,
     bit for bit, those rows of the whole frame rendered on one device; the shard's sample count is 1/8 of the frame's."""
     from spira_hip import distributed as D
     s = scenes.scene_s3()

@@ -27,7 +27,7 @@ def test_multi_one_device_through_rccl_equals_render(gpu, prec):
 
 @pytest.mark.parametrize("n", [2, 3, 8])
 def test_multi_rehearsal_any_n_is_bit_identical(gpu, n):
-    """Ragged heights (117 = 14 stripes of 8 + 5 rows) so that ranks own different numbers of rows."""
+    """Ragged heights (117 and 200 rows over 2, 3, 8 devices) so that ranks own different numbers of rows."""
     s = scenes.scene_s4(level=3)
     ns, nm, nt = _counts(s)
     os.environ["SPIRA_MULTI_REHEARSE"] = "1"
