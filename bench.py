@@ -489,6 +489,28 @@ def main():
                     scene_build[pr] = json.loads(r.stdout.strip().splitlines()[-1])
                 except (IndexError, ValueError):
                     scene_build[pr] = {"error": (r.stderr or r.stdout)[-400:]}
+        # ---- what a rank's render of an 8-GPU run costs (N=1 only, the headline shape): this GPU renders each of the 8 ranks' tiles of the weak-scaling
+        # workload (spp 64 x 8 on rows r, r + 8, ...) in turn; the step of the 8-GPU run costs the slowest rank's render plus the exchange (not measurable here)
+        tiles8 = None
+        if world == 1 and not args.no_extras and (W, H) == (1920, 1080) and cfg["scaling"] == "weak":
+            ms8 = []
+            for r8 in range(8):
+                t8 = D.tile_params(H, 8, r8)
+                p8 = B.make_params(W, H, spp_cfg * 8, depth, *counts, flags=kflags[args.kernel] | B.POST_NONE | ext_flags, seed=seed, **t8)
+                o8 = torch.empty((3, t8["rows"], W), dtype=tdt[args.prec], device="cuda")
+                for _ in range(3):                 # (a configuration's first launches run slower)
+                    scene_h.render_device(sc[3], p8, o8.data_ptr(), 0, stream.cuda_stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    scene_h.render_device(sc[3], p8, o8.data_ptr(), 0, stream.cuda_stream)
+                torch.cuda.synchronize()
+                ms8.append((time.perf_counter() - t1) / 5 * 1e3)
+            tiles8 = {"world": 8, "spp": spp_cfg * 8, "rows_per_rank": sorted(set(D.tile_params(H, 8, r8)["rows"] for r8 in range(8))),
+                      "tile_render_ms": {"max": round(max(ms8), 3), "min": round(min(ms8), 3)}, "frame_ms_one_gpu": round(dt / args.steps * 1e3, 3),
+                      "render_bound_of_weak_scaling_efficiency": round(dt / args.steps * 1e3 / max(ms8), 4),
+                      "what": "each of the 8 ranks' tiles of `bench.py --gpus 8` rendered on this one GPU in turn (same samples per rank as the one-GPU frame): "
+                              "frame_ms / slowest tile bounds the weak-scaling efficiency from the render side; the gather (6.2 MB per rank over xGMI) comes on top"}
         # ---- CPU baseline leg (rank 0, N=1 only): the oracle port on the host cores, bounded sample
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -527,7 +549,7 @@ def main():
                        "width": W, "height": H, "spp": spp_total, "max_depth": depth, "scene": scene_name, "kernel": args.kernel,
                        "samples_per_step": samples_per_step, "segments_per_step_rank0": c_timed["segments"],
                        "passes_per_step": c_timed["passes"], "launches_per_step": c_timed["launches"]},
-            "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "scene_build": scene_build, "configs": other_configs, "other_precision": alt, "stress": stress, "stress_mesh": stress_mesh, "extensions": extensions,
+            "roofline": roof, "cpu_baseline": cpu, "end_to_end": end_to_end, "scene_build": scene_build, "tiles_of_8_gpus": tiles8, "configs": other_configs, "other_precision": alt, "stress": stress, "stress_mesh": stress_mesh, "extensions": extensions,
             "organisations": orgs, "estimators": estimators, "per_rank": per_rank, "kernel_source_hash": src_hash,
         }
         print(json.dumps(result), flush=True)
