@@ -39,6 +39,8 @@ def test_default_line_has_the_contract_keys_and_is_consistent():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert d["end_to_end"]["ms"] > d["ms_per_step"] * 0.5 and d["end_to_end"]["d2h_bytes"] == 3 * 1920 * 1080 * 8
+    t8 = d["tiles_of_8_gpus"]      # every rank's tile of `--gpus 8` rendered here in turn: 135 rows each, about what the frame costs
+    assert t8["rows_per_rank"] == [135] and t8["spp"] == 512 and 0.7 < t8["render_bound_of_weak_scaling_efficiency"] < 1.15
     for cname, scene, spp, depth in (("c4", "scene s3", 256, 8), ("c5", "scene s4", 64, 12)):
         e = d["configs"][cname]
         assert scene in e["workload"] and "spp=%d depth=%d" % (spp, depth) in e["metric"]
